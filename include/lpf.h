@@ -1,0 +1,131 @@
+/*
+ * lpf.h -- C ABI of the MI355X LiDAR projection + instance point-filter library
+ * (liblpf.so, built from lidar_object_detection_amd/csrc/).
+ *
+ * The reference (KaranSankla/Lidar_Object_Detection) has no FFI: its hot path is a
+ * run of inline NumPy statements and small Python functions inside each script's
+ * frame loop.  This header is the narrowest data cut that contains that path; each
+ * entry point names the reference statements it replaces (paths relative to
+ * /root/reference/Coding_testes).  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, caller-owned buffers, no exceptions: every call returns LPF_OK (0) or
+ *     a negative lpf_status; lpf_last_error() gives the text.
+ *   - a context is bound to one GPU and one HIP stream; it is not thread-safe.
+ *     One context per GPU / rank.
+ *   - "on_device" flags say whether the pointers of that call are device (HBM)
+ *     pointers.  With device outputs lpf_run* only enqueues work on the context's
+ *     stream and returns; call lpf_sync() (or synchronise the stream you attached
+ *     with lpf_set_stream) before reading.  With host pointers the call stages
+ *     through internal HBM buffers and is synchronous.
+ *   - a batch is F frames that share the camera; points of all frames are
+ *     concatenated, frame f owns points [frame_off[f], frame_off[f+1]).
+ */
+#ifndef LPF_H
+#define LPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
+#define LPF_ABI_VERSION 1
+
+typedef enum lpf_status {
+    LPF_OK = 0,
+    LPF_ERR_ARG = -1,             /* bad argument (null, negative, M > 32, ...) */
+    LPF_ERR_HIP = -2,             /* a HIP runtime call failed */
+    LPF_ERR_STATE = -3,           /* camera / masks / boxes not set for this call */
+    LPF_ERR_NOMEM = -4            /* device or host allocation failed */
+} lpf_status;
+
+typedef struct lpf_ctx lpf_ctx;
+
+/* Per-frame scalar results (host or device memory, see lpf_outputs.on_device). */
+typedef struct lpf_frame_summary {
+    int64_t n_valid;                        /* len(valid_indices), V3:585 */
+    int64_t n_labelled;                     /* points in >=1 mask == bg_assigned.sum(), V4:290-298 */
+    int64_t inst_count[LPF_MAX_MASKS];      /* len(car_point_sets[m]), V3:227-231 */
+    int64_t inst_off[LPF_MAX_MASKS + 1];    /* list m = inst_idx[inst_off[m] .. inst_off[m+1]) */
+    int64_t best_cnt[LPF_MAX_MASKS];        /* best_match_count, V3:353-376 (0 if none) */
+    int32_t best_box[LPF_MAX_MASKS];        /* best_bbox_idx into the frame's box list, -1 if none */
+    int32_t inst_overflow;                  /* 1 if sum(inst_count) > inst_cap: lists truncated */
+    int32_t reserved;
+} lpf_frame_summary;
+
+/* Output buffers of lpf_run / lpf_run_batch.  Any pointer may be NULL (not wanted).
+ * Ntot = frame_off[F]; Btot = total boxes over the batch. */
+typedef struct lpf_outputs {
+    int32_t  *uv;          /* [Ntot][2]  (u, v) = np.round(x/|z|), np.round(y/|z|)  (V3:568-569),
+                              saturated to int32 (only ever differs from the reference's int64
+                              for |pixel| >= 2^31, which is never a valid point) */
+    uint32_t *label_bits;  /* [Ntot]     bit m set <=> point valid and inside mask m (V3:225); 0 if !valid */
+    double   *depth;       /* [Ntot]     signed depth incl. the 0 -> -1e-6 patch (cam2image) */
+    double   *u_f;         /* [Ntot]     x/|z| before rounding */
+    double   *v_f;         /* [Ntot]     y/|z| before rounding */
+    int64_t  *valid_idx;   /* [Ntot]     frame f's np.where(valid)[0] at valid_idx[frame_off[f] ...],
+                                          indices relative to the frame, ascending (V3:585) */
+    int64_t  *inst_idx;    /* [F][inst_cap]  per frame: instance lists, concatenated in mask order,
+                                          each ascending (== valid_indices[mask_indices], V3:225-228) */
+    int64_t   inst_cap;    /*            capacity per frame of inst_idx (entries) */
+    int32_t  *count_mb;    /* [M * Btot] frame f's [M][B_f] block at M*box_off[f]:
+                                          np.sum(oriented_point_in_bbox(car_points_m, box_b)), V3:366-370 */
+    lpf_frame_summary *summary;  /* [F] */
+    int32_t   on_device;   /* 1: all pointers above are device pointers, call is asynchronous */
+    int32_t   reserved;
+} lpf_outputs;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+int  lpf_abi_version(void);
+int  lpf_create(lpf_ctx **out, int device_id);
+void lpf_destroy(lpf_ctx *ctx);
+const char *lpf_last_error(const lpf_ctx *ctx);      /* ctx may be NULL: error of the last failed lpf_create */
+/* Run on a stream the caller owns (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int  lpf_set_stream(lpf_ctx *ctx, void *hip_stream);
+int  lpf_sync(lpf_ctx *ctx);
+
+/* ---- per-sequence state --------------------------------------------------------
+ * Replaces V3:565-569 + V3:584 constants.  T = TrVeloToRect (row-major 4x4, V3:535),
+ * K = camera.K[:3,:3] (row-major 3x3), W,H = camera.width/height,
+ * valid <=> 0<=u<W && 0<=v<H && depth > depth_min_excl && depth < depth_max_excl
+ * (reference: 0 and 50, or 0 and 30 in V4/V5). */
+int lpf_set_camera(lpf_ctx *ctx, const double T_velo_to_rect[16], const double K[9],
+                   int W, int H, double depth_min_excl, double depth_max_excl);
+
+/* ---- per-frame (or per-batch) state --------------------------------------------
+ * Masks of F frames, M <= 32 per frame (pad with all-zero masks), each H x W.
+ * u8: nonzero = member.  f32: the reference's float masks;
+ *   v3_pipeline = 0 : member <=> mask.astype(np.uint8) != 0                  (V3:222-225 on raw masks, V2/V4)
+ *   v3_pipeline = 1 : (mask*255).astype(uint8) -> erode -> /255.0 -> astype(uint8) != 0   (V3:82-97 then V3:222)
+ * erode_iters: iterations of cv2.erode with the 3x3 MORPH_ELLIPSE (cross) element (V3:83-90).
+ * The packed result is a uint32 label image [F][H][W], bit m = mask m, kept in HBM. */
+int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode_iters, int on_device);
+int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int v3_pipeline,
+                      int erode_iters, int on_device);
+/* Pre-packed label images [F][H][W] (bit m = mask m). */
+int lpf_set_label_image(lpf_ctx *ctx, const uint32_t *label, int F, int M, int on_device);
+/* Read back the label images currently held ([F][H][W]); for tests of the pack/erode kernels. */
+int lpf_get_label_image(lpf_ctx *ctx, uint32_t *out, int on_device);
+
+/* Box corners in the velodyne frame, f64 [Btot][8][3] in the dataset's corner order
+ * (output of transform_bboxes_to_velodyne, V3:41-52); frame f owns boxes
+ * [box_off[f], box_off[f+1]).  oriented = 1: oriented_point_in_bbox (V3:167-204, the
+ * three skewed slabs c1-c0, c3-c0, c4-c0); 0: point_in_bbox (V3:143-164).  Host pointers. */
+int lpf_set_boxes(lpf_ctx *ctx, const double *corners_velo, const int32_t *box_off, int F, int oriented);
+
+/* ---- the hot path ----------------------------------------------------------------
+ * Replaces, per frame: V3:565-569 (transform + cam2image), V3:584-592 (clip, np.where),
+ * extract_car_points_by_mask (V3:211-233), the oriented_point_in_bbox counting loop and
+ * best-box scan of calculate_car_point_statistics (V3:344-379).
+ * pts: f32 [Ntot][4] (x, y, z, reflectance) exactly as read from the .bin (V3:28). */
+int lpf_run(lpf_ctx *ctx, const float *pts, int64_t N, int pts_on_device, const lpf_outputs *out);
+int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int F,
+                  int pts_on_device, const lpf_outputs *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPF_H */

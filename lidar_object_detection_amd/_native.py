@@ -1,0 +1,305 @@
+"""ctypes binding of liblpf.so (include/lpf.h) -- the only route to the hot path.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the
+calls raise.  NumPy arrays go through the ABI's host-pointer mode; torch CUDA (ROCm)
+tensors are passed by ``data_ptr()`` in device mode.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+LPF_MAX_MASKS = 32
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+
+
+class LpfError(RuntimeError):
+    """An lpf_* call returned a negative status (message from lpf_last_error)."""
+
+    def __init__(self, code, msg):
+        super().__init__("liblpf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FrameSummary(ctypes.Structure):
+    _fields_ = [("n_valid", _I64), ("n_labelled", _I64),
+                ("inst_count", _I64 * LPF_MAX_MASKS), ("inst_off", _I64 * (LPF_MAX_MASKS + 1)),
+                ("best_cnt", _I64 * LPF_MAX_MASKS), ("best_box", ctypes.c_int32 * LPF_MAX_MASKS),
+                ("inst_overflow", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+SUMMARY_DTYPE = np.dtype([("n_valid", "<i8"), ("n_labelled", "<i8"), ("inst_count", "<i8", (32,)),
+                          ("inst_off", "<i8", (33,)), ("best_cnt", "<i8", (32,)), ("best_box", "<i4", (32,)),
+                          ("inst_overflow", "<i4"), ("reserved", "<i4")])
+assert SUMMARY_DTYPE.itemsize == ctypes.sizeof(FrameSummary) == 928
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [("uv", _P), ("label_bits", _P), ("depth", _P), ("u_f", _P), ("v_f", _P),
+                ("valid_idx", _P), ("inst_idx", _P), ("inst_cap", _I64), ("count_mb", _P),
+                ("summary", _P), ("on_device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen liblpf.so; raises if it has not been built (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LpfError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU path" % path)
+    lib = ctypes.CDLL(path)
+    lib.lpf_last_error.restype = ctypes.c_char_p
+    lib.lpf_last_error.argtypes = [_P]
+    lib.lpf_create.argtypes = [ctypes.POINTER(_P), ctypes.c_int]
+    lib.lpf_destroy.argtypes = [_P]
+    lib.lpf_destroy.restype = None
+    lib.lpf_set_stream.argtypes = [_P, _P]
+    lib.lpf_sync.argtypes = [_P]
+    lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_label_image.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.lpf_get_label_image.argtypes = [_P, _P, ctypes.c_int]
+    lib.lpf_set_boxes.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int]
+    lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
+    lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
+    _lib = lib
+    return lib
+
+
+EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync",
+            "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
+            "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch")
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dev_ptr(t, dtype_name=None):
+    """data_ptr of a contiguous torch ROCm tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("device buffers must be contiguous torch tensors on the GPU")
+    if dtype_name is not None and str(t.dtype) != "torch." + dtype_name:
+        raise ValueError("expected torch.%s, got %s" % (dtype_name, t.dtype))
+    return t.data_ptr()
+
+
+class LpfContext:
+    """One context = one GPU + one stream (not thread-safe): the C ABI, object-shaped."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = _P()
+        rc = self._lib.lpf_create(ctypes.byref(h), int(device))
+        if rc != 0:
+            raise LpfError(rc, (self._lib.lpf_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+        self.W = self.H = 0
+        self.M = 0
+        self.F_masks = 0
+        self.box_off = None
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise LpfError(rc, (self._lib.lpf_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lpf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.lpf_set_stream(self._h, _P(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        self._check(self._lib.lpf_sync(self._h))
+
+    # -- state ------------------------------------------------------------------------
+    def set_camera(self, T_velo_to_rect, K, width, height, depth_min=0.0, depth_max=50.0):
+        T = np.ascontiguousarray(T_velo_to_rect, dtype=np.float64).reshape(16)
+        K3 = np.ascontiguousarray(np.asarray(K, dtype=np.float64)[:3, :3]).reshape(9)
+        self._check(self._lib.lpf_set_camera(self._h, T.ctypes.data, K3.ctypes.data, int(width), int(height),
+                                             float(depth_min), float(depth_max)))
+        self.W, self.H = int(width), int(height)
+
+    def set_masks(self, masks, erode_iters=0, v3_pipeline=False):
+        """masks: [M,H,W] or [F,M,H,W]; uint8/bool (nonzero = member) or float32 (reference masks).
+        NumPy array, or torch tensor already on the GPU."""
+        dev = _is_torch(masks)
+        shape = tuple(masks.shape)
+        if len(shape) == 3:
+            shape = (1,) + shape
+        if len(shape) != 4 or (shape[1] and shape[2:] != (self.H, self.W)):
+            raise ValueError("masks must be [M,%d,%d] or [F,M,%d,%d], got %s" % (self.H, self.W, self.H, self.W, shape))
+        F, M = shape[0], shape[1]
+        if dev:
+            is_f = str(masks.dtype) == "torch.float32"
+            if not is_f and str(masks.dtype) not in ("torch.uint8", "torch.bool"):
+                raise ValueError("device masks must be float32, uint8 or bool")
+            ptr = _dev_ptr(masks) if M else None
+            keep = masks
+        else:
+            a = np.asarray(masks)
+            is_f = a.dtype.kind == "f"
+            a = np.ascontiguousarray(a, dtype=np.float32 if is_f else np.uint8)
+            ptr = a.ctypes.data if M else None
+            keep = a
+        if is_f:
+            rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, int(bool(v3_pipeline)), int(erode_iters), int(dev))
+        else:
+            rc = self._lib.lpf_set_masks_u8(self._h, ptr, F, M, int(erode_iters), int(dev))
+        del keep
+        self._check(rc)
+        self.F_masks, self.M = F, M
+
+    def clear_masks(self):
+        self._check(self._lib.lpf_set_masks_u8(self._h, None, 0, 0, 0, 0))
+        self.F_masks, self.M = 0, 0
+
+    def set_label_image(self, label, M):
+        a = np.ascontiguousarray(label, dtype=np.uint32)
+        if a.ndim == 2:
+            a = a[None]
+        if a.shape[1:] != (self.H, self.W):
+            raise ValueError("label image must be [F,%d,%d]" % (self.H, self.W))
+        self._check(self._lib.lpf_set_label_image(self._h, a.ctypes.data, a.shape[0], int(M), 0))
+        self.F_masks, self.M = a.shape[0], int(M)
+
+    def get_label_image(self):
+        out = np.empty((self.F_masks, self.H, self.W), np.uint32)
+        self._check(self._lib.lpf_get_label_image(self._h, out.ctypes.data, 0))
+        return out
+
+    def set_boxes(self, corners_per_frame, oriented=True):
+        """corners_per_frame: list (one entry per frame) of f64 [B_f,8,3] velodyne-frame corners,
+        or a single [B,8,3] array for a one-frame run."""
+        if isinstance(corners_per_frame, np.ndarray):
+            corners_per_frame = [corners_per_frame]
+        arrs = [np.asarray(c, dtype=np.float64).reshape(-1, 8, 3) for c in corners_per_frame]
+        off = np.zeros(len(arrs) + 1, np.int32)
+        off[1:] = np.cumsum([a.shape[0] for a in arrs])
+        cat = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if arrs else np.zeros((0, 8, 3))
+        self._check(self._lib.lpf_set_boxes(self._h, cat.ctypes.data if cat.size else None, off.ctypes.data,
+                                            len(arrs), int(bool(oriented))))
+        self.box_off = off
+
+    def clear_boxes(self):
+        self._check(self._lib.lpf_set_boxes(self._h, None, None, 0, 1))
+        self.box_off = None
+
+    # -- the hot path, host arrays ------------------------------------------------------
+    def run(self, points, **kw):
+        """One frame of f32[N,4] host points -> dict of NumPy results (see run_batch)."""
+        return self.run_batch([points], **kw)[0]
+
+    def run_batch(self, frames, want_uv=True, want_label=True, want_float=False, want_lists=True,
+                  inst_cap=None):
+        """frames: list of f32[N_f,4] arrays.  Returns one dict per frame with
+        u, v (int32), label_bits, valid_idx, inst_lists, inst_count, count_mb, best_box, best_cnt,
+        n_valid, n_labelled (+ depth, uf, vf with want_float)."""
+        frames = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 4) for p in frames]
+        F = len(frames)
+        off = np.zeros(F + 1, np.int64)
+        off[1:] = np.cumsum([p.shape[0] for p in frames])
+        n = int(off[-1])
+        pts = np.concatenate(frames, axis=0) if F > 1 else frames[0]
+        M = self.M if self.F_masks else 0
+        Btot = int(self.box_off[-1]) if self.box_off is not None else 0
+        if inst_cap is None:
+            inst_cap = max(int(max(p.shape[0] for p in frames)), 1)
+        while True:
+            o = Outputs()
+            o.on_device = 0
+            uv = np.empty((n, 2), np.int32) if want_uv else None
+            lab = np.empty(n, np.uint32) if want_label else None
+            dep = np.empty(n, np.float64) if want_float else None
+            uf = np.empty(n, np.float64) if want_float else None
+            vf = np.empty(n, np.float64) if want_float else None
+            vidx = np.empty(n, np.int64) if want_lists else None
+            iidx = np.empty((F, inst_cap), np.int64) if (want_lists and M) else None
+            cmb = np.zeros(max(M * Btot, 1), np.int32)
+            summ = np.zeros(F, SUMMARY_DTYPE)
+            for name, arr in (("uv", uv), ("label_bits", lab), ("depth", dep), ("u_f", uf), ("v_f", vf),
+                              ("valid_idx", vidx), ("inst_idx", iidx), ("count_mb", cmb), ("summary", summ)):
+                setattr(o, name, arr.ctypes.data if arr is not None else None)
+            o.inst_cap = inst_cap
+            self._check(self._lib.lpf_run_batch(self._h, pts.ctypes.data if n else None, off.ctypes.data, F, 0,
+                                                ctypes.byref(o)))
+            if iidx is not None and summ["inst_overflow"].any():
+                inst_cap = int(summ["inst_off"][:, 32].max())      # exact size now known: run again
+                continue
+            break
+        res = []
+        for f in range(F):
+            a, b = int(off[f]), int(off[f + 1])
+            s = summ[f]
+            r = dict(n_valid=int(s["n_valid"]), n_labelled=int(s["n_labelled"]),
+                     inst_count=s["inst_count"][:M].copy(), best_box=s["best_box"][:M].copy(),
+                     best_cnt=s["best_cnt"][:M].copy())
+            if want_uv:
+                r["u"], r["v"] = uv[a:b, 0], uv[a:b, 1]
+            if want_label:
+                r["label_bits"] = lab[a:b]
+            if want_float:
+                r["depth"], r["uf"], r["vf"] = dep[a:b], uf[a:b], vf[a:b]
+            if want_lists:
+                r["valid_idx"] = vidx[a:a + r["n_valid"]]
+                r["inst_lists"] = [iidx[f, int(s["inst_off"][m]):int(s["inst_off"][m + 1])] for m in range(M)] \
+                    if iidx is not None else []
+            if self.box_off is not None:
+                b0, b1 = int(self.box_off[f]), int(self.box_off[f + 1])
+                r["count_mb"] = cmb[M * b0:M * b1].reshape(M, b1 - b0).astype(np.int64)
+            else:
+                r["count_mb"] = np.zeros((M, 0), np.int64)
+            res.append(r)
+        return res
+
+    # -- the hot path, device tensors (asynchronous) -------------------------------------
+    def run_device(self, pts, frame_off, uv=None, label_bits=None, depth=None, u_f=None, v_f=None,
+                   valid_idx=None, inst_idx=None, inst_cap=0, count_mb=None, summary=None):
+        """Enqueue one batch on the context's stream.  pts: torch float32 [Ntot,4] on the GPU;
+        outputs: preallocated torch tensors (None = not wanted); summary: uint8 [F*928].
+        frame_off: int64 NumPy/sequence [F+1] (host)."""
+        off = np.ascontiguousarray(frame_off, dtype=np.int64)
+        F = off.shape[0] - 1
+        o = Outputs()
+        o.on_device = 1
+        o.uv = _dev_ptr(uv, "int32")
+        o.label_bits = _dev_ptr(label_bits)
+        o.depth, o.u_f, o.v_f = _dev_ptr(depth, "float64"), _dev_ptr(u_f, "float64"), _dev_ptr(v_f, "float64")
+        o.valid_idx = _dev_ptr(valid_idx, "int64")
+        o.inst_idx = _dev_ptr(inst_idx, "int64")
+        o.inst_cap = int(inst_cap)
+        o.count_mb = _dev_ptr(count_mb, "int32")
+        o.summary = _dev_ptr(summary)
+        self._check(self._lib.lpf_run_batch(self._h, _dev_ptr(pts, "float32"), off.ctypes.data, F, 1,
+                                            ctypes.byref(o)))

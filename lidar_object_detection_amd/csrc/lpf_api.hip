@@ -1,0 +1,487 @@
+// lpf_api.hip -- host side of liblpf.so: the C ABI of include/lpf.h over the gfx950
+// kernels in lpf_kernels.hip.h.  No CPU compute path exists here: every entry point
+// either launches HIP kernels or fails with an error code.
+#include "lpf_kernels.hip.h"
+#include "../../include/lpf.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_k3_finalize");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {                       // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct lpf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    bool have_camera = false;
+    double T[12], K[9], dmin = 0, dmax = 0;
+    int W = 0, H = 0;
+
+    // masks -> label images
+    int mask_F = 0, mask_M = 0;       // 0 frames = no masks set
+    DevBuf label_a, label_b;          // [F][H][W] uint32 (b = erosion ping-pong)
+    uint32_t *label_cur = nullptr;
+    DevBuf mask_stage;
+
+    // boxes
+    int box_F = 0, oriented = 1;
+    std::vector<int32_t> box_off;     // F+1
+    DevBuf boxp;                      // [Btot][16] double
+
+    // per-run scratch
+    DevBuf frames, vbal, mbal, seg_cnt, seg_inst, inst_total, cnt, label_scratch;
+    // host-io staging
+    DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
+    std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
+};
+
+namespace {
+
+int fail(lpf_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define LPF_HIP(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), LPF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// grow-only; new memory is zeroed (the self-cleaning counters rely on it)
+int reserve(lpf_ctx *c, DevBuf &b, size_t bytes, bool zero = false)
+{
+    if (bytes <= b.cap && b.p) return LPF_OK;
+    if (bytes == 0) bytes = 256;
+    if (b.p) {
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 4;        // headroom against regrowth
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, LPF_ERR_NOMEM, "hipMalloc(%zu) failed", want);
+    }
+    b.cap = want;
+    if (zero) LPF_HIP(c, hipMemsetAsync(b.p, 0, want, c->stream));
+    return LPF_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+int use_device(lpf_ctx *c)
+{
+    LPF_HIP(c, hipSetDevice(c->device));
+    return LPF_OK;
+}
+
+// box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside)
+void box_params(const double *c, int oriented, double *o)
+{
+    for (int i = 0; i < 16; ++i) o[i] = 0.0;
+    if (oriented) {
+        static const int other[3] = {1, 3, 4};
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+        for (int a = 0; a < 3; ++a) {
+            const double *q = c + 3 * other[a];
+            const double v0 = q[0] - c[0], v1 = q[1] - c[1], v2 = q[2] - c[2];
+            double vv = v0 * v0; vv = std::fma(v1, v1, vv); vv = std::fma(v2, v2, vv);
+            o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = vv;
+        }
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            double lo = c[k], hi = c[k];
+            for (int j = 1; j < 8; ++j) {
+                const double w = c[3 * j + k];
+                if (w < lo) lo = w;
+                if (w > hi) hi = w;
+            }
+            o[k] = lo; o[3 + k] = hi;
+        }
+    }
+}
+
+template <typename T>
+int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode_iters, int on_device)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called before masks (W, H)");
+    if (F < 0 || M < 0 || M > LPF_MAX_MASKS || erode_iters < 0 || (F > 0 && M > 0 && !masks))
+        return fail(c, LPF_ERR_ARG, "set_masks: F=%d M=%d erode_iters=%d masks=%p", F, M, erode_iters, (const void *)masks);
+    c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr;
+    if (F == 0) return LPF_OK;
+    const size_t hw = (size_t)c->H * c->W;
+    int rc;
+    if ((rc = reserve(c, c->label_a, (size_t)F * hw * 4))) return rc;
+    const T *d_masks = masks;
+    if (M > 0 && !on_device) {
+        const size_t bytes = (size_t)F * M * hw * sizeof(T);
+        if ((rc = reserve(c, c->mask_stage, bytes))) return rc;
+        LPF_HIP(c, hipMemcpyAsync(c->mask_stage.p, masks, bytes, hipMemcpyHostToDevice, c->stream));
+        d_masks = (const T *)c->mask_stage.p;
+    }
+    dim3 grid((c->W + LPF_TW - 1) / LPF_TW, (c->H + LPF_TH - 1) / LPF_TH, F);
+    uint32_t *cur = (uint32_t *)c->label_a.p;
+    if (M == 0) {
+        LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * 4, c->stream));
+    } else {
+        const int fuse = erode_iters > 0 ? 1 : 0;
+        if (mode == 0)
+            hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+        else if (mode == 1)
+            hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+        else
+            hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+        LPF_HIP(c, hipGetLastError());
+        if (erode_iters > 1) {
+            if ((rc = reserve(c, c->label_b, (size_t)F * hw * 4))) return rc;
+            uint32_t *other = (uint32_t *)c->label_b.p;
+            for (int it = 1; it < erode_iters; ++it) {
+                hipLaunchKernelGGL(lpf_erode_packed, grid, dim3(LPF_BLOCK), 0, c->stream, cur, other, c->H, c->W);
+                LPF_HIP(c, hipGetLastError());
+                uint32_t *t = cur; cur = other; other = t;
+            }
+        }
+    }
+    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
+    c->label_cur = cur;
+    c->mask_F = F; c->mask_M = M;
+    return LPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lpf_abi_version(void) { return LPF_ABI_VERSION; }
+
+int lpf_create(lpf_ctx **out, int device_id)
+{
+    if (!out) return fail(nullptr, LPF_ERR_ARG, "lpf_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, LPF_ERR_HIP, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, LPF_ERR_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    lpf_ctx *c = new (std::nothrow) lpf_ctx();
+    if (!c) return fail(nullptr, LPF_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(nullptr, LPF_ERR_HIP, "stream creation failed: %s", hipGetErrorString(e));
+        delete c;
+        return LPF_ERR_HIP;
+    }
+    c->own_stream = true;
+    *out = c;
+    return LPF_OK;
+}
+
+void lpf_destroy(lpf_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->frames, &c->vbal, &c->mbal, &c->seg_cnt,
+                     &c->seg_inst, &c->inst_total, &c->cnt, &c->label_scratch, &c->st_pts, &c->st_uv, &c->st_label,
+                     &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
+    for (DevBuf *b : all) release(*b);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *lpf_last_error(const lpf_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int lpf_set_stream(lpf_ctx *c, void *s)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (s) {
+        c->stream = (hipStream_t)s;
+    } else {
+        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return LPF_OK;
+}
+
+int lpf_sync(lpf_ctx *c)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    return LPF_OK;
+}
+
+int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int H, double dmin, double dmax)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
+        return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
+    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr; }   // label images are W x H
+    memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
+    memcpy(c->K, K, sizeof c->K);
+    c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
+    c->have_camera = true;
+    return LPF_OK;
+}
+
+int lpf_set_masks_u8(lpf_ctx *c, const uint8_t *masks, int F, int M, int erode_iters, int on_device)
+{
+    return set_masks_impl<uint8_t>(c, masks, F, M, 0, erode_iters, on_device);
+}
+
+int lpf_set_masks_f32(lpf_ctx *c, const float *masks, int F, int M, int v3_pipeline, int erode_iters, int on_device)
+{
+    return set_masks_impl<float>(c, masks, F, M, v3_pipeline ? 2 : 1, erode_iters, on_device);
+}
+
+int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_device)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called first");
+    if (F < 0 || M < 0 || M > LPF_MAX_MASKS || (F > 0 && !label)) return fail(c, LPF_ERR_ARG, "set_label_image: F=%d M=%d", F, M);
+    c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr;
+    if (F == 0) return LPF_OK;
+    const size_t bytes = (size_t)F * c->H * c->W * 4;
+    int rc;
+    if ((rc = reserve(c, c->label_a, bytes))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(c->label_a.p, label, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));
+    c->label_cur = (uint32_t *)c->label_a.p;
+    c->mask_F = F; c->mask_M = M;
+    return LPF_OK;
+}
+
+int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
+{
+    if (!c || !out) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->label_cur) return fail(c, LPF_ERR_STATE, "no masks set");
+    const size_t bytes = (size_t)c->mask_F * c->H * c->W * 4;
+    LPF_HIP(c, hipMemcpyAsync(out, c->label_cur, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    return LPF_OK;
+}
+
+int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int F, int oriented)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "set_boxes: F=%d box_off=%p", F, (const void *)box_off);
+    c->box_F = 0; c->box_off.clear();
+    if (F == 0) return LPF_OK;
+    if (box_off[0] != 0) return fail(c, LPF_ERR_ARG, "set_boxes: box_off[0] must be 0");
+    for (int f = 0; f < F; ++f)
+        if (box_off[f + 1] < box_off[f]) return fail(c, LPF_ERR_ARG, "set_boxes: box_off not ascending at %d", f);
+    const int Btot = box_off[F];
+    if (Btot > 0 && !corners) return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL");
+    std::vector<double> bp((size_t)Btot * 16);
+    for (int b = 0; b < Btot; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16);
+    int rc;
+    if ((rc = reserve(c, c->boxp, bp.size() * sizeof(double)))) return rc;
+    if (Btot > 0) {
+        LPF_HIP(c, hipMemcpyAsync(c->boxp.p, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        LPF_HIP(c, hipStreamSynchronize(c->stream));      // bp is a local
+    }
+    c->box_off.assign(box_off, box_off + F + 1);
+    c->box_F = F; c->oriented = oriented ? 1 : 0;
+    return LPF_OK;
+}
+
+int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F, int pts_on_device, const lpf_outputs *out)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera has not been called");
+    if (!out || !frame_off || F <= 0) return fail(c, LPF_ERR_ARG, "run: out=%p frame_off=%p F=%d", (const void *)out, (const void *)frame_off, F);
+    if (frame_off[0] != 0) return fail(c, LPF_ERR_ARG, "run: frame_off[0] must be 0");
+    for (int f = 0; f < F; ++f) {
+        const int64_t n = frame_off[f + 1] - frame_off[f];
+        if (n < 0 || n > 0x7fffffffll - LPF_CHUNK) return fail(c, LPF_ERR_ARG, "run: frame %d has %lld points", f, (long long)n);
+    }
+    const int64_t Ntot = frame_off[F];
+    if (Ntot > 0 && !pts) return fail(c, LPF_ERR_ARG, "run: pts is NULL");
+    if (c->mask_F != 0 && c->mask_F != F) return fail(c, LPF_ERR_STATE, "masks were set for %d frames, run has %d", c->mask_F, F);
+    if (c->box_F != 0 && c->box_F != F) return fail(c, LPF_ERR_STATE, "boxes were set for %d frames, run has %d", c->box_F, F);
+    if (out->inst_idx && out->inst_cap <= 0) return fail(c, LPF_ERR_ARG, "run: inst_idx given with inst_cap=%lld", (long long)out->inst_cap);
+    const int M = c->mask_F ? c->mask_M : 0;
+    const int Btot = c->box_F ? c->box_off[F] : 0;
+    const bool host_io = !out->on_device;
+    int rc;
+
+    // ---- segmentation: <= ~1024 segments, multiples of the K1 chunk --------------------
+    const int64_t target = 1024;
+    int64_t seg_pts = (Ntot + target - 1) / target;
+    seg_pts = ((seg_pts + LPF_CHUNK - 1) / LPF_CHUNK) * LPF_CHUNK;
+    if (seg_pts < LPF_CHUNK) seg_pts = LPF_CHUNK;
+    c->h_frames.resize(F);
+    int nseg_total = 0;
+    for (int f = 0; f < F; ++f) {
+        LpfFrame &fr = c->h_frames[f];
+        fr.pt_off = frame_off[f];
+        fr.N = (int)(frame_off[f + 1] - frame_off[f]);
+        fr.seg_off = nseg_total;
+        fr.nseg = (int)((fr.N + seg_pts - 1) / seg_pts);
+        nseg_total += fr.nseg;
+        fr.box_off = c->box_F ? c->box_off[f] : 0;
+        fr.B = c->box_F ? c->box_off[f + 1] - c->box_off[f] : 0;
+        fr.inst_base = (long long)f * out->inst_cap;
+        fr.pad = 0;
+    }
+    const int nseg_cap = nseg_total > 0 ? nseg_total : 1;
+    const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
+
+    if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
+    if ((rc = reserve(c, c->vbal, rows * 8))) return rc;
+    if ((rc = reserve(c, c->mbal, rows * 8))) return rc;
+    if ((rc = reserve(c, c->seg_cnt, (size_t)nseg_cap * sizeof(uint2)))) return rc;
+    if ((rc = reserve(c, c->seg_inst, (size_t)32 * nseg_cap * 4))) return rc;
+    if ((rc = reserve(c, c->inst_total, (size_t)F * 32 * 4, true))) return rc;
+    if ((rc = reserve(c, c->cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
+
+    LpfParams P;
+    memset(&P, 0, sizeof P);
+    memcpy(P.T, c->T, sizeof P.T);
+    memcpy(P.K, c->K, sizeof P.K);
+    P.dmin = c->dmin; P.dmax = c->dmax; P.W = c->W; P.H = c->H;
+    P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap;
+    P.oriented = c->oriented; P.inst_cap = out->inst_cap;
+    P.frames = (const LpfFrame *)c->frames.p;
+    P.label_img = (M > 0) ? c->label_cur : nullptr;
+    P.boxp = (const double *)c->boxp.p;
+    P.vbal = (unsigned long long *)c->vbal.p; P.mbal = (unsigned long long *)c->mbal.p;
+    P.seg_cnt = (uint2 *)c->seg_cnt.p; P.seg_inst = (unsigned *)c->seg_inst.p;
+    P.inst_total = (unsigned *)c->inst_total.p; P.cnt = (unsigned *)c->cnt.p;
+
+    // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
+    const size_t n = (size_t)Ntot;
+    if (pts_on_device) {
+        P.pts = (const float4 *)pts;
+    } else {
+        if ((rc = reserve(c, c->st_pts, n * 16))) return rc;
+        if (n) LPF_HIP(c, hipMemcpyAsync(c->st_pts.p, pts, n * 16, hipMemcpyHostToDevice, c->stream));
+        P.pts = (const float4 *)c->st_pts.p;
+    }
+#define LPF_OUTBUF(field, member, stage, bytes)                                   \
+    if (out->member) {                                                            \
+        if (host_io) {                                                            \
+            if ((rc = reserve(c, c->stage, (bytes)))) return rc;                  \
+            P.field = (decltype(P.field))c->stage.p;                              \
+        } else {                                                                  \
+            P.field = (decltype(P.field))out->member;                             \
+        }                                                                         \
+    }
+    LPF_OUTBUF(uv, uv, st_uv, n * 8)
+    LPF_OUTBUF(label_bits, label_bits, st_label, n * 4)
+    LPF_OUTBUF(depth, depth, st_depth, n * 8)
+    LPF_OUTBUF(uf, u_f, st_uf, n * 8)
+    LPF_OUTBUF(vf, v_f, st_vf, n * 8)
+    LPF_OUTBUF(valid_idx, valid_idx, st_valid, n * 8)
+    LPF_OUTBUF(inst_idx, inst_idx, st_inst, (size_t)F * (size_t)out->inst_cap * 8)
+    LPF_OUTBUF(count_out, count_mb, st_count, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4)
+    // the summary is always produced: host callers need it to size the list copies
+    if (host_io || !out->summary) {
+        if ((rc = reserve(c, c->st_summary, (size_t)F * sizeof(lpf_frame_summary)))) return rc;
+        P.summary = c->st_summary.p;
+    } else {
+        P.summary = out->summary;
+    }
+#undef LPF_OUTBUF
+    if (!P.label_bits) {                 // K2 re-reads the labels of masked points
+        if ((rc = reserve(c, c->label_scratch, n * 4))) return rc;
+        P.label_bits = (uint32_t *)c->label_scratch.p;
+    }
+
+    // The frame table only changes when the batch geometry does; upload it then (and wait, the
+    // source is pageable host memory that the next call rewrites).
+    if (c->h_frames_dev.size() != c->h_frames.size() ||
+        memcmp(c->h_frames_dev.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) != 0) {
+        LPF_HIP(c, hipMemcpyAsync(c->frames.p, c->h_frames.data(), (size_t)F * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        c->h_frames_dev = c->h_frames;
+    }
+    if (nseg_total > 0) {
+        hipLaunchKernelGGL(lpf_k1_project, dim3(nseg_total), dim3(LPF_BLOCK), 0, c->stream, P);
+        LPF_HIP(c, hipGetLastError());
+        if (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0)) {
+            hipLaunchKernelGGL(lpf_k2_lists, dim3(nseg_total), dim3(LPF_BLOCK), 0, c->stream, P);
+            LPF_HIP(c, hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(64), 0, c->stream, P);
+    LPF_HIP(c, hipGetLastError());
+
+    if (host_io) {
+#define LPF_D2H(member, field, bytes) \
+    if (out->member && (bytes)) LPF_HIP(c, hipMemcpyAsync(out->member, P.field, (bytes), hipMemcpyDeviceToHost, c->stream));
+        LPF_D2H(uv, uv, n * 8)
+        LPF_D2H(label_bits, label_bits, n * 4)
+        LPF_D2H(depth, depth, n * 8)
+        LPF_D2H(u_f, uf, n * 8)
+        LPF_D2H(v_f, vf, n * 8)
+        LPF_D2H(count_mb, count_out, (size_t)M * Btot * 4)
+        // lists: fetch the summary first, then only the filled part of each list
+        std::vector<lpf_frame_summary> hs((size_t)F);
+        LPF_HIP(c, hipMemcpyAsync(hs.data(), P.summary, (size_t)F * sizeof(lpf_frame_summary), hipMemcpyDeviceToHost, c->stream));
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        for (int f = 0; f < F; ++f) {
+            const size_t nv = (size_t)hs[f].n_valid;
+            if (out->valid_idx && nv)
+                LPF_HIP(c, hipMemcpyAsync(out->valid_idx + frame_off[f], P.valid_idx + frame_off[f], nv * 8,
+                                          hipMemcpyDeviceToHost, c->stream));
+            int64_t tot = hs[f].inst_off[LPF_MAX_MASKS];
+            if (tot > out->inst_cap) tot = out->inst_cap;
+            if (out->inst_idx && tot > 0)
+                LPF_HIP(c, hipMemcpyAsync(out->inst_idx + (size_t)f * out->inst_cap, P.inst_idx + (size_t)f * out->inst_cap,
+                                          (size_t)tot * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (out->summary) memcpy(out->summary, hs.data(), (size_t)F * sizeof(lpf_frame_summary));
+#undef LPF_D2H
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return LPF_OK;
+}
+
+int lpf_run(lpf_ctx *c, const float *pts, int64_t N, int pts_on_device, const lpf_outputs *out)
+{
+    const int64_t off[2] = {0, N};
+    return lpf_run_batch(c, pts, off, 1, pts_on_device, out);
+}
+
+}  // extern "C"
