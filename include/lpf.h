@@ -125,6 +125,14 @@ int lpf_run(lpf_ctx *ctx, const float *pts, int64_t N, int pts_on_device, const 
 int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int F,
                   int pts_on_device, const lpf_outputs *out);
 
+/* ---- measurement -------------------------------------------------------------------
+ * With profiling on, every lpf_run* brackets its project+label kernel (lpf_k1_project, the
+ * dominant kernel) with HIP events on the context's stream.  lpf_profile_read waits for the
+ * stream, returns the summed elapsed milliseconds and the number of bracketed launches
+ * since the last reset.  (No reference counterpart: the reference has no timers.) */
+int lpf_profile_enable(lpf_ctx *ctx, int on);
+int lpf_profile_read(lpf_ctx *ctx, double *k1_ms_sum, int64_t *k1_launches, int reset);
+
 #ifdef __cplusplus
 }
 #endif

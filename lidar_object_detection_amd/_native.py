@@ -75,13 +75,16 @@ def load():
     lib.lpf_set_boxes.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int]
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
+    lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
+    lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
     _lib = lib
     return lib
 
 
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
-            "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch")
+            "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
+            "lpf_profile_enable", "lpf_profile_read")
 
 
 def _is_torch(x):
@@ -142,6 +145,15 @@ class LpfContext:
 
     def sync(self):
         self._check(self._lib.lpf_sync(self._h))
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.lpf_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        """(summed milliseconds, launches) of the event-bracketed project+label kernel."""
+        ms, n = ctypes.c_double(0.0), _I64(0)
+        self._check(self._lib.lpf_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
+        return ms.value, int(n.value)
 
     # -- state ------------------------------------------------------------------------
     def set_camera(self, T_velo_to_rect, K, width, height, depth_min=0.0, depth_max=50.0):
@@ -303,3 +315,44 @@ class LpfContext:
         o.summary = _dev_ptr(summary)
         self._check(self._lib.lpf_run_batch(self._h, _dev_ptr(pts, "float32"), off.ctypes.data, F, 1,
                                             ctypes.byref(o)))
+
+    def make_device_step(self, pts, frame_off, masks_u8=None, erode_iters=0, **outs):
+        """Pre-marshal one device-mode step (optional u8 mask pack + run_batch) and return a
+        zero-argument callable that only performs the C calls -- for launch-bound loops."""
+        off = np.ascontiguousarray(frame_off, dtype=np.int64)
+        F = off.shape[0] - 1
+        o = Outputs()
+        o.on_device = 1
+        o.uv = _dev_ptr(outs.get("uv"), "int32")
+        o.label_bits = _dev_ptr(outs.get("label_bits"))
+        o.depth, o.u_f, o.v_f = (_dev_ptr(outs.get("depth"), "float64"), _dev_ptr(outs.get("u_f"), "float64"),
+                                 _dev_ptr(outs.get("v_f"), "float64"))
+        o.valid_idx = _dev_ptr(outs.get("valid_idx"), "int64")
+        o.inst_idx = _dev_ptr(outs.get("inst_idx"), "int64")
+        o.inst_cap = int(outs.get("inst_cap", 0))
+        o.count_mb = _dev_ptr(outs.get("count_mb"), "int32")
+        o.summary = _dev_ptr(outs.get("summary"))
+        lib, h, check = self._lib, self._h, self._check
+        p_pts, p_off, p_out = _P(_dev_ptr(pts, "float32")), _P(off.ctypes.data), ctypes.byref(o)
+        run, setm = lib.lpf_run_batch, lib.lpf_set_masks_u8
+        if masks_u8 is not None:
+            shape = tuple(masks_u8.shape)
+            if len(shape) == 3:
+                shape = (1,) + shape
+            if shape[0] != F or shape[2:] != (self.H, self.W) or str(masks_u8.dtype) != "torch.uint8":
+                raise ValueError("masks_u8 must be a torch.uint8 GPU tensor [F,M,H,W]")
+            p_m, M, it = _P(_dev_ptr(masks_u8)), shape[1], int(erode_iters)
+            self.F_masks, self.M = F, M
+
+            def fn(_keep=(off, o, pts, masks_u8, outs)):
+                rc = setm(h, p_m, F, M, it, 1)
+                if rc == 0:
+                    rc = run(h, p_pts, p_off, F, 1, p_out)
+                if rc:
+                    check(rc)
+        else:
+            def fn(_keep=(off, o, pts, outs)):
+                rc = run(h, p_pts, p_off, F, 1, p_out)
+                if rc:
+                    check(rc)
+        return fn

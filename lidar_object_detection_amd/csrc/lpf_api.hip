@@ -45,12 +45,19 @@ struct lpf_ctx {
     int box_F = 0, oriented = 1;
     std::vector<int32_t> box_off;     // F+1
     DevBuf boxp;                      // [Btot][16] double
+    DevBuf boxq;                      // [Btot][8] float conservative AABB
 
     // per-run scratch
-    DevBuf frames, vbal, mbal, seg_cnt, seg_inst, inst_total, cnt, label_scratch;
+    DevBuf frames, segs, vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, label_scratch;
     // host-io staging
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
+    std::vector<LpfFrame> h_segs;
+
+    // optional event bracketing of K1 (lpf_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;       // pairs: ev[2i] before, ev[2i+1] after
+    size_t ev_used = 0;               // pairs recorded since the last reset
 };
 
 namespace {
@@ -106,30 +113,72 @@ int use_device(lpf_ctx *c)
     return LPF_OK;
 }
 
-// box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside)
-void box_params(const double *c, int oriented, double *o)
+// box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) plus a
+// conservative float AABB of the accepted region, used only to skip hopeless (point, box) pairs.
+void box_params(const double *c, int oriented, double *o, float *q)
 {
     for (int i = 0; i < 16; ++i) o[i] = 0.0;
+    double lo[3], hi[3];
+    bool bounded = true;
     if (oriented) {
         static const int other[3] = {1, 3, 4};
         o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+        double V[3][3], vv[3];
+        bool ok = true;
         for (int a = 0; a < 3; ++a) {
-            const double *q = c + 3 * other[a];
-            const double v0 = q[0] - c[0], v1 = q[1] - c[1], v2 = q[2] - c[2];
-            double vv = v0 * v0; vv = std::fma(v1, v1, vv); vv = std::fma(v2, v2, vv);
-            o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = vv;
+            const double *p = c + 3 * other[a];
+            const double v0 = p[0] - c[0], v1 = p[1] - c[1], v2 = p[2] - c[2];
+            double w = v0 * v0; w = std::fma(v1, v1, w); w = std::fma(v2, v2, w);
+            o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = w;
+            V[a][0] = v0; V[a][1] = v1; V[a][2] = v2; vv[a] = w;
+            if (!(w >= 1e-200 && w <= 1e200)) ok = false;      // also false for NaN
+        }
+        o[15] = ok ? 1.0 : 0.0;            // 1: "0 <= d <= vv" decides the slab exactly (see kernel comment)
+        // region = { p : 0 <= (p-c0).v_a <= vv_a }: vertices solve V x = sigma*vv, sigma in {0,1}^3
+        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+        const double scale = std::sqrt(vv[0]) * std::sqrt(vv[1]) * std::sqrt(vv[2]);
+        if (!ok || !(std::fabs(det) > 1e-6 * scale)) {
+            bounded = false;
+        } else {
+            double inv[3][3];
+            inv[0][0] = (V[1][1] * V[2][2] - V[1][2] * V[2][1]) / det; inv[0][1] = (V[0][2] * V[2][1] - V[0][1] * V[2][2]) / det;
+            inv[0][2] = (V[0][1] * V[1][2] - V[0][2] * V[1][1]) / det; inv[1][0] = (V[1][2] * V[2][0] - V[1][0] * V[2][2]) / det;
+            inv[1][1] = (V[0][0] * V[2][2] - V[0][2] * V[2][0]) / det; inv[1][2] = (V[0][2] * V[1][0] - V[0][0] * V[1][2]) / det;
+            inv[2][0] = (V[1][0] * V[2][1] - V[1][1] * V[2][0]) / det; inv[2][1] = (V[0][1] * V[2][0] - V[0][0] * V[2][1]) / det;
+            inv[2][2] = (V[0][0] * V[1][1] - V[0][1] * V[1][0]) / det;
+            for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
+            for (int sg = 0; sg < 8; ++sg) {
+                const double r[3] = {(sg & 1) ? vv[0] : 0.0, (sg & 2) ? vv[1] : 0.0, (sg & 4) ? vv[2] : 0.0};
+                for (int k = 0; k < 3; ++k) {
+                    const double x = c[k] + inv[k][0] * r[0] + inv[k][1] * r[1] + inv[k][2] * r[2];
+                    if (x < lo[k]) lo[k] = x;
+                    if (x > hi[k]) hi[k] = x;
+                }
+            }
         }
     } else {
         for (int k = 0; k < 3; ++k) {
-            double lo = c[k], hi = c[k];
+            double a = c[k], b = c[k];
             for (int j = 1; j < 8; ++j) {
                 const double w = c[3 * j + k];
-                if (w < lo) lo = w;
-                if (w > hi) hi = w;
+                if (w < a) a = w;
+                if (w > b) b = w;
             }
-            o[k] = lo; o[3 + k] = hi;
+            o[k] = a; o[3 + k] = b; lo[k] = a; hi[k] = b;
+            if (!(a == a) || !(b == b)) bounded = false;
         }
     }
+    for (int k = 0; k < 3; ++k) {
+        if (!bounded || !std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+            q[k] = -INFINITY; q[4 + k] = INFINITY;
+        } else {
+            const double m = 1e-5 * (std::fabs(lo[k]) + std::fabs(hi[k]) + (hi[k] - lo[k])) + 1e-6;
+            q[k] = std::nextafterf((float)(lo[k] - m), -INFINITY);
+            q[4 + k] = std::nextafterf((float)(hi[k] + m), INFINITY);
+        }
+    }
+    q[3] = 0.f; q[7] = 0.f;
 }
 
 template <typename T>
@@ -157,18 +206,32 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (M == 0) {
         LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * 4, c->stream));
     } else {
-        const int fuse = erode_iters > 0 ? 1 : 0;
-        if (mode == 0)
-            hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
-        else if (mode == 1)
-            hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
-        else
-            hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+        int left = erode_iters;
+        if (hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
+            // streaming pack, 16 pixels per lane; erosion (if any) then runs on the packed image
+            const long long total16 = (long long)F * (long long)(hw / 16);
+            const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+            if (mode == 0)
+                hipLaunchKernelGGL((lpf_pack16<T, 0>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+            else if (mode == 1)
+                hipLaunchKernelGGL((lpf_pack16<T, 1>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+            else
+                hipLaunchKernelGGL((lpf_pack16<T, 2>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+        } else {
+            const int fuse = erode_iters > 0 ? 1 : 0;
+            left -= fuse;
+            if (mode == 0)
+                hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+            else if (mode == 1)
+                hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+            else
+                hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+        }
         LPF_HIP(c, hipGetLastError());
-        if (erode_iters > 1) {
+        if (left > 0) {
             if ((rc = reserve(c, c->label_b, (size_t)F * hw * 4))) return rc;
             uint32_t *other = (uint32_t *)c->label_b.p;
-            for (int it = 1; it < erode_iters; ++it) {
+            for (int it = 0; it < left; ++it) {
                 hipLaunchKernelGGL(lpf_erode_packed, grid, dim3(LPF_BLOCK), 0, c->stream, cur, other, c->H, c->W);
                 LPF_HIP(c, hipGetLastError());
                 uint32_t *t = cur; cur = other; other = t;
@@ -214,10 +277,11 @@ void lpf_destroy(lpf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->frames, &c->vbal, &c->mbal, &c->seg_cnt,
-                     &c->seg_inst, &c->inst_total, &c->cnt, &c->label_scratch, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->frames, &c->vbal, &c->mbal,
+                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->label_scratch, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -312,12 +376,15 @@ int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int
     const int Btot = box_off[F];
     if (Btot > 0 && !corners) return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL");
     std::vector<double> bp((size_t)Btot * 16);
-    for (int b = 0; b < Btot; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16);
+    std::vector<float> bq((size_t)Btot * 8);
+    for (int b = 0; b < Btot; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data() + (size_t)b * 8);
     int rc;
     if ((rc = reserve(c, c->boxp, bp.size() * sizeof(double)))) return rc;
+    if ((rc = reserve(c, c->boxq, bq.size() * sizeof(float)))) return rc;
     if (Btot > 0) {
         LPF_HIP(c, hipMemcpyAsync(c->boxp.p, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));      // bp is a local
+        LPF_HIP(c, hipMemcpyAsync(c->boxq.p, bq.data(), bq.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        LPF_HIP(c, hipStreamSynchronize(c->stream));      // bp, bq are locals
     }
     c->box_off.assign(box_off, box_off + F + 1);
     c->box_F = F; c->oriented = oriented ? 1 : 0;
@@ -333,7 +400,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (frame_off[0] != 0) return fail(c, LPF_ERR_ARG, "run: frame_off[0] must be 0");
     for (int f = 0; f < F; ++f) {
         const int64_t n = frame_off[f + 1] - frame_off[f];
-        if (n < 0 || n > 0x7fffffffll - LPF_CHUNK) return fail(c, LPF_ERR_ARG, "run: frame %d has %lld points", f, (long long)n);
+        if (n < 0 || n > 0x7fffffffll - LPF_SEG_QUANTUM) return fail(c, LPF_ERR_ARG, "run: frame %d has %lld points", f, (long long)n);
     }
     const int64_t Ntot = frame_off[F];
     if (Ntot > 0 && !pts) return fail(c, LPF_ERR_ARG, "run: pts is NULL");
@@ -345,11 +412,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool host_io = !out->on_device;
     int rc;
 
-    // ---- segmentation: <= ~1024 segments, multiples of the K1 chunk --------------------
-    const int64_t target = 1024;
-    int64_t seg_pts = (Ntot + target - 1) / target;
-    seg_pts = ((seg_pts + LPF_CHUNK - 1) / LPF_CHUNK) * LPF_CHUNK;
-    if (seg_pts < LPF_CHUNK) seg_pts = LPF_CHUNK;
+    // ---- segmentation: fixed 2048-point segments (K2 blocks); K1 tiles subdivide them ------
+    const int64_t seg_pts = LPF_SEG_QUANTUM;
     c->h_frames.resize(F);
     int nseg_total = 0;
     for (int f = 0; f < F; ++f) {
@@ -362,7 +426,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.box_off = c->box_F ? c->box_off[f] : 0;
         fr.B = c->box_F ? c->box_off[f + 1] - c->box_off[f] : 0;
         fr.inst_base = (long long)f * out->inst_cap;
-        fr.pad = 0;
+        fr.pad = f;
     }
     const int nseg_cap = nseg_total > 0 ? nseg_total : 1;
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
@@ -370,9 +434,10 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
     if ((rc = reserve(c, c->vbal, rows * 8))) return rc;
     if ((rc = reserve(c, c->mbal, rows * 8))) return rc;
-    if ((rc = reserve(c, c->seg_cnt, (size_t)nseg_cap * sizeof(uint2)))) return rc;
-    if ((rc = reserve(c, c->seg_inst, (size_t)32 * nseg_cap * 4))) return rc;
-    if ((rc = reserve(c, c->inst_total, (size_t)F * 32 * 4, true))) return rc;
+    if ((rc = reserve(c, c->seg_tab, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4), true))) return rc;
+    if ((rc = reserve(c, c->seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
+    if ((rc = reserve(c, c->frame_tot, (size_t)F * LPF_TAB_ROWS * 4))) return rc;
+    if (F > 1 && (rc = reserve(c, c->segs, (size_t)nseg_cap * sizeof(LpfFrame)))) return rc;
     if ((rc = reserve(c, c->cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
 
     LpfParams P;
@@ -382,12 +447,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.dmin = c->dmin; P.dmax = c->dmax; P.W = c->W; P.H = c->H;
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
-    P.frames = (const LpfFrame *)c->frames.p;
+    P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
     P.label_img = (M > 0) ? c->label_cur : nullptr;
-    P.boxp = (const double *)c->boxp.p;
+    P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.vbal = (unsigned long long *)c->vbal.p; P.mbal = (unsigned long long *)c->mbal.p;
-    P.seg_cnt = (uint2 *)c->seg_cnt.p; P.seg_inst = (unsigned *)c->seg_inst.p;
-    P.inst_total = (unsigned *)c->inst_total.p; P.cnt = (unsigned *)c->cnt.p;
+    P.seg_tab = (uint4 *)c->seg_tab.p; P.seg_pre = (uint4 *)c->seg_pre.p; P.frame_tot = (unsigned *)c->frame_tot.p;
+    P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)c->cnt.p;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -433,18 +498,44 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (c->h_frames_dev.size() != c->h_frames.size() ||
         memcmp(c->h_frames_dev.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) != 0) {
         LPF_HIP(c, hipMemcpyAsync(c->frames.p, c->h_frames.data(), (size_t)F * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
+        if (F > 1) {                                      // per-segment copy of the owning frame's record
+            c->h_segs.resize((size_t)nseg_total);
+            for (int f = 0; f < F; ++f)
+                for (int sg = 0; sg < c->h_frames[f].nseg; ++sg) c->h_segs[(size_t)c->h_frames[f].seg_off + sg] = c->h_frames[f];
+            if (nseg_total)
+                LPF_HIP(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), (size_t)nseg_total * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
+        }
         LPF_HIP(c, hipStreamSynchronize(c->stream));
         c->h_frames_dev = c->h_frames;
     }
     if (nseg_total > 0) {
-        hipLaunchKernelGGL(lpf_k1_project, dim3(nseg_total), dim3(LPF_BLOCK), 0, c->stream, P);
-        LPF_HIP(c, hipGetLastError());
-        if (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0)) {
-            hipLaunchKernelGGL(lpf_k2_lists, dim3(nseg_total), dim3(LPF_BLOCK), 0, c->stream, P);
-            LPF_HIP(c, hipGetLastError());
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->profiling && c->ev_used < (1u << 16)) {
+            if (c->ev.size() < 2 * (c->ev_used + 1)) {
+                hipEvent_t a, b;
+                LPF_HIP(c, hipEventCreate(&a));
+                LPF_HIP(c, hipEventCreate(&b));
+                c->ev.push_back(a); c->ev.push_back(b);
+            }
+            e0 = c->ev[2 * c->ev_used]; e1 = c->ev[2 * c->ev_used + 1];
+            ++c->ev_used;
+            LPF_HIP(c, hipEventRecord(e0, c->stream));
         }
+        // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
+        if (Ntot <= (4ll << 20))
+            hipLaunchKernelGGL((lpf_k1_project_t<2, LPF_K1_FLAGS>), dim3(nseg_total * (unsigned)(seg_pts / 512)), dim3(LPF_BLOCK), 0, c->stream, P);
+        else
+            hipLaunchKernelGGL((lpf_k1_project_t<4, LPF_K1_FLAGS>), dim3(nseg_total * (unsigned)(seg_pts / 1024)), dim3(LPF_BLOCK), 0, c->stream, P);
+        LPF_HIP(c, hipGetLastError());
+        if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
     }
-    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(64), 0, c->stream, P);
+    hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+    LPF_HIP(c, hipGetLastError());
+    if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
+        hipLaunchKernelGGL(lpf_k2_lists, dim3((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES), dim3(LPF_BLOCK), 0, c->stream, P);
+        LPF_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
     LPF_HIP(c, hipGetLastError());
 
     if (host_io) {
@@ -475,6 +566,30 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 #undef LPF_D2H
         LPF_HIP(c, hipStreamSynchronize(c->stream));
     }
+    return LPF_OK;
+}
+
+int lpf_profile_enable(lpf_ctx *c, int on)
+{
+    if (!c) return LPF_ERR_ARG;
+    c->profiling = on != 0;
+    return LPF_OK;
+}
+
+int lpf_profile_read(lpf_ctx *c, double *k1_ms_sum, int64_t *k1_launches, int reset)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        LPF_HIP(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+        sum += ms;
+    }
+    if (k1_ms_sum) *k1_ms_sum = sum;
+    if (k1_launches) *k1_launches = (int64_t)c->ev_used;
+    if (reset) c->ev_used = 0;
     return LPF_OK;
 }
 

@@ -2,7 +2,9 @@
 // instance point-filter path.  Included by lpf_api.hip only.
 //
 // Kernel map (reference statements: /root/reference/Coding_testes, see include/lpf.h)
-//   lpf_pack_erode_*   masks -> uint32 label image, 3x3-cross erosion in an LDS tile   (V3:82-97, V3:222)
+//   lpf_pack16 / lpf_pack_erode / lpf_erode_packed
+//                      masks -> uint32 label image (bit m = mask m); 3x3-cross erosion
+//                      on an LDS-staged tile of packed bits                             (V3:82-97, V3:222)
 //   lpf_k1_project     float4 stream: 4x4 transform, cam2image, clip, label gather,
 //                      per-row wave ballots + per-segment counters                      (V3:565-569, 584, 225)
 //   lpf_k2_lists       ballots -> stable valid / per-instance index lists (wave prefix),
@@ -17,10 +19,9 @@
 #include <stdint.h>
 
 #define LPF_BLOCK 256            // 4 waves of 64
-#define LPF_CHUNK_ROWS 4         // K1: float4 loads in flight per lane
-#define LPF_CHUNK (LPF_BLOCK * LPF_CHUNK_ROWS)   // 1024 points
-#define LPF_K2_BATCH 4096        // K2: points per LDS batch (64 ballot rows)
-#define LPF_K2_ROWS (LPF_K2_BATCH / 64)
+#define LPF_SEG_QUANTUM 2048     // points per segment (K2 block); every K1 tile size divides it
+#define LPF_TAB_ROWS 36          // counters per segment: 0 valid, 1 masked, 2+m instance m (34 used)
+#define LPF_TAB_GROUPS 9         // stored as uint4 groups: counter c lives in group c>>2, component c&3
 
 struct LpfFrame {                // one per frame, device + host copy
     long long pt_off;            // first point of the frame in the concatenated arrays
@@ -30,7 +31,7 @@ struct LpfFrame {                // one per frame, device + host copy
     int nseg;                    // segments of the frame
     int box_off;                 // first box of the frame
     int B;                       // boxes of the frame
-    int pad;
+    int pad;                     // frame index (set by the host)
 };
 
 struct LpfParams {
@@ -39,15 +40,18 @@ struct LpfParams {
     double dmin, dmax;
     int W, H;
     int F, M;
-    int seg_pts;                 // points per segment (multiple of LPF_CHUNK)
+    int seg_pts;                 // points per segment (= LPF_SEG_QUANTUM)
     int nseg_total;
-    int nseg_cap;                // row pitch of seg_inst
+    int nseg_cap;                // pitch (segments) of one seg_tab group
     int oriented;
     long long inst_cap;
-    const LpfFrame *frames;
+    LpfFrame frame0;             // the frame table by value when F == 1 (no dependent load)
+    const LpfFrame *frames;      // [F]
+    const LpfFrame *segs;        // [nseg_total] the owning frame's record per segment (pad = frame id)
     const float4 *pts;
     const uint32_t *label_img;   // [F][H][W] or null
-    const double *boxp;          // [Btot][16]
+    const double *boxp;          // [Btot][16] exact box parameters
+    const float *boxq;           // [Btot][8]  conservative float AABB {lo xyz, hi xyz}
     // outputs (nullable)
     int2 *uv;
     uint32_t *label_bits;
@@ -58,9 +62,10 @@ struct LpfParams {
     void *summary;               // lpf_frame_summary[F]
     // scratch
     unsigned long long *vbal, *mbal;   // one 64-bit ballot per 64 points
-    uint2 *seg_cnt;              // per segment {n_valid, n_masked}
-    unsigned *seg_inst;          // [32][nseg_cap] per-segment per-instance counts
-    unsigned *inst_total;        // [F][32]
+    uint4 *seg_tab;              // [LPF_TAB_GROUPS][nseg_cap] per-segment counters, 4 per uint4;
+                                 // K1 tiles add into it, K3 leaves it zeroed
+    uint4 *seg_pre;              // [LPF_TAB_GROUPS][nseg_cap] written by the scan (see lpf_scan_segments)
+    unsigned *frame_tot;         // [F][LPF_TAB_ROWS] totals per frame
     unsigned *cnt;               // [M*Btot] inside counts (self-cleaned by K3)
 };
 
@@ -85,117 +90,219 @@ __device__ __forceinline__ int lpf_find_frame(const LpfFrame *frames, int F, int
     return lo;
 }
 
+// int32 pixel convention of the ABI: saturate, NaN -> INT32_MIN.  v_cvt_i32_f64 saturates
+// out-of-range inputs by itself (and gives 0 for NaN); r is already integral (rint).
 __device__ __forceinline__ int32_t lpf_sat_i32(double r)
 {
-    if (r != r) return INT32_MIN;
-    if (r >= 2147483647.0) return INT32_MAX;
-    if (r <= -2147483648.0) return INT32_MIN;
-    return (int32_t)r;
+    int v;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(v) : "v"(r));
+    return (r != r) ? INT32_MIN : v;
+}
+
+// biased exponent in [723, 1323]  <=>  2^-300 <= |x| < 2^301 (finite, normal, non-zero)
+__device__ __forceinline__ bool lpf_mid_range(double x)
+{
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    return (e - 723u) <= 600u;
+}
+
+// (qx/ad, qy/ad), both correctly rounded.  The compiler's IEEE f64 division is
+// div_scale -> rcp -> two Newton steps -> mul -> residual fma -> div_fmas -> div_fixup;
+// when all operands are mid-range the scale/fixup steps are identities, so the same
+// arithmetic with ONE shared reciprocal gives the same bits for both quotients at about
+// half the instructions.  Anything else (zeros, subnormals, inf, nan, huge ratios) takes
+// the plain '/' operator.
+__device__ __forceinline__ void lpf_div2(double qx, double qy, double ad, double &uf, double &vf)
+{
+    if (lpf_mid_range(ad) && lpf_mid_range(qx) && lpf_mid_range(qy)) {
+        double r = __builtin_amdgcn_rcp(ad);
+        double e = fma(-ad, r, 1.0); r = fma(r, e, r);
+        e = fma(-ad, r, 1.0);        r = fma(r, e, r);
+        double q = qx * r; double s = fma(-ad, q, qx); uf = fma(s, r, q);
+        q = qy * r;        s = fma(-ad, q, qy);        vf = fma(s, r, q);
+    } else {
+        uf = qx / ad;
+        vf = qy / ad;
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// K1: one block = one segment of one frame, streamed in chunks of 1024 points.
+// K1: one block = one segment of one frame, streamed in chunks of 2048 points: all eight
+// float4 loads of a lane are issued before the first use, the label gathers of the chunk
+// are issued together, and only then do the ballots / label stores consume them.
 // Algorithmic HBM bytes per point: 16 (xyzI) + 8 (u,v) + 4 (label) = 28, + 0.25 (ballots).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project(const LpfParams P)
+// FL bits: production flags first, the LAB_* ones only exist for tools/k1_lab.hip ablations.
+#define LPF_F_X4 1u          // keep the reflectance lane alive: 16-byte loads instead of 12
+#define LPF_F_NTLOAD 2u      // nontemporal point loads
+#define LPF_F_NTSTORE 4u     // nontemporal output stores
+#define LPF_F_LAB_NOMATH 8u
+#define LPF_F_LAB_NOGATHER 16u
+#define LPF_F_LAB_NOSTORE 32u
+
+#define LPF_F_LAB_NOBAL 64u
+#define LPF_F_LAB_NOTAB 128u
+
+template <int ROWS, unsigned FL>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
 {
-    __shared__ unsigned s_nvalid, s_nmask, s_inst[32];
+    // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
+    __shared__ unsigned s_cnt[LPF_TAB_ROWS];
+    constexpr int TILE = LPF_BLOCK * ROWS;
+    static_assert(LPF_SEG_QUANTUM % TILE == 0, "tiles must divide segments");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const int sid = lpf_xcd_remap(blockIdx.x, P.nseg_total);
-    const int f = lpf_find_frame(P.frames, P.F, sid);
-    const LpfFrame fr = P.frames[f];
+    const int tiles_per_seg = P.seg_pts / TILE;
+    const int lb = lpf_xcd_remap(blockIdx.x, P.nseg_total * tiles_per_seg);
+    const int sid = lb / tiles_per_seg;
+    LpfFrame fr = P.frame0;
+    if (P.F > 1) fr = P.segs[sid];                                       // one scalar load, no search
+    const int f = fr.pad;
     const int seg_start = (sid - fr.seg_off) * P.seg_pts;
     const int seg_end = min(seg_start + P.seg_pts, fr.N);
+    const int c = seg_start + (lb - sid * tiles_per_seg) * TILE;       // first point of the tile
+    if (c >= seg_end) return;                                            // padding tile of a short segment
     const float4 *__restrict__ pts = P.pts + fr.pt_off;
     const uint32_t *__restrict__ limg =
         (P.label_img && P.M > 0) ? P.label_img + (size_t)f * (size_t)P.W * (size_t)P.H : nullptr;
     const int rows_per_seg = P.seg_pts >> 6;
     const double Wd = (double)P.W, Hd = (double)P.H;
 
-    if (tid < 32) s_inst[tid] = 0;
-    if (tid == 0) { s_nvalid = 0; s_nmask = 0; }
+    if (tid < LPF_TAB_ROWS) s_cnt[tid] = 0;
     __syncthreads();
     unsigned nvalid_w = 0, nmask_w = 0;
 
-    for (int c = seg_start; c < seg_end; c += LPF_CHUNK) {
-        float4 p[LPF_CHUNK_ROWS];
+    // a wave owns ROWS consecutive rows of 64 points: its ballots form one contiguous run
+    {
+        const int wbase = c + wave * (ROWS * 64) + lane;
+        float4 p[ROWS];
 #pragma unroll
-        for (int r = 0; r < LPF_CHUNK_ROWS; ++r) {
-            // clamp instead of branching: all four loads issue back to back, one wait
-            const int idx = c + r * LPF_BLOCK + tid;
-            p[r] = pts[min(idx, seg_end - 1)];
+        for (int r = 0; r < ROWS; ++r) {
+            // clamp instead of branching: the loads issue back to back, waits are counted
+            const float4 *src = pts + min(wbase + r * 64, seg_end - 1);
+            if (FL & LPF_F_NTLOAD) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src));
+                p[r] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                p[r] = *src;
+            }
         }
+        uint32_t lab[ROWS];
+        bool valid[ROWS];
 #pragma unroll
-        for (int r = 0; r < LPF_CHUNK_ROWS; ++r) {
-            const int idx = c + r * LPF_BLOCK + tid;
+        for (int r = 0; r < ROWS; ++r) {
+            const int idx = wbase + r * 64;
             const bool live = idx < seg_end;
-            const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
-            // K1: rows of T as k-ordered fma chains (= OpenBLAS dgemm on this shape)
-            double cx = P.T[0] * x; cx = fma(P.T[1], y, cx); cx = fma(P.T[2],  z, cx); cx = cx + P.T[3];
-            double cy = P.T[4] * x; cy = fma(P.T[5], y, cy); cy = fma(P.T[6],  z, cy); cy = cy + P.T[7];
-            double cz = P.T[8] * x; cz = fma(P.T[9], y, cz); cz = fma(P.T[10], z, cz); cz = cz + P.T[11];
-            // K2: cam2image
-            double qx = P.K[0] * cx; qx = fma(P.K[1], cy, qx); qx = fma(P.K[2], cz, qx);
-            double qy = P.K[3] * cx; qy = fma(P.K[4], cy, qy); qy = fma(P.K[5], cz, qy);
-            double d  = P.K[6] * cx; d  = fma(P.K[7], cy, d);  d  = fma(P.K[8], cz, d);
-            if (d == 0.0) d = -1e-6;
-            const double ad = fabs(d);
-            const double uf = qx / ad, vf = qy / ad;
-            const double ru = rint(uf), rv = rint(vf);          // np.round: half to even
+            if (FL & LPF_F_X4) asm volatile("" ::"v"(p[r].w));
+            double uf, vf, d, ru, rv;
+            if (FL & LPF_F_LAB_NOMATH) {
+                uf = (double)p[r].x; vf = (double)p[r].y; d = (double)p[r].z;
+                ru = uf + 700.0; rv = vf + 100.0;
+            } else {
+                const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
+                // K1: rows of T as k-ordered fma chains (= OpenBLAS dgemm on this shape)
+                double cx = P.T[0] * x; cx = fma(P.T[1], y, cx); cx = fma(P.T[2],  z, cx); cx = cx + P.T[3];
+                double cy = P.T[4] * x; cy = fma(P.T[5], y, cy); cy = fma(P.T[6],  z, cy); cy = cy + P.T[7];
+                double cz = P.T[8] * x; cz = fma(P.T[9], y, cz); cz = fma(P.T[10], z, cz); cz = cz + P.T[11];
+                // K2: cam2image
+                double qx = P.K[0] * cx; qx = fma(P.K[1], cy, qx); qx = fma(P.K[2], cz, qx);
+                double qy = P.K[3] * cx; qy = fma(P.K[4], cy, qy); qy = fma(P.K[5], cz, qy);
+                d = P.K[6] * cx; d = fma(P.K[7], cy, d); d = fma(P.K[8], cz, d);
+                if (d == 0.0) d = -1e-6;
+                lpf_div2(qx, qy, fabs(d), uf, vf);
+                ru = rint(uf); rv = rint(vf);                   // np.round: half to even
+            }
             // K3: clip
-            const bool valid = live && (ru >= 0.0) && (ru < Wd) && (rv >= 0.0) && (rv < Hd) &&
-                               (d > P.dmin) && (d < P.dmax);
-            // K4: label gather (2.1 MB image, L2 resident)
-            uint32_t lab = 0;
-            if (valid && limg) lab = limg[(int)rv * P.W + (int)ru];
-            if (live) {
+            const bool ok = live && (ru >= 0.0) && (ru < Wd) && (rv >= 0.0) && (rv < Hd) &&
+                            (d > P.dmin) && (d < P.dmax);
+            valid[r] = ok;
+            // K4: label gather (2.1 MB image, L2 resident); consumed after the loop
+            lab[r] = 0;
+            if (!(FL & LPF_F_LAB_NOGATHER)) {
+                if (ok && limg) lab[r] = limg[(int)rv * P.W + (int)ru];
+            }
+            if (live && !(FL & LPF_F_LAB_NOSTORE)) {
                 const long long g = fr.pt_off + idx;
-                if (P.uv) P.uv[g] = make_int2(lpf_sat_i32(ru), lpf_sat_i32(rv));
-                if (P.label_bits) P.label_bits[g] = lab;
+                if (P.uv) {
+                    if (FL & LPF_F_NTSTORE) {
+                        typedef int i2v __attribute__((ext_vector_type(2)));
+                        i2v t; t.x = lpf_sat_i32(ru); t.y = lpf_sat_i32(rv);
+                        __builtin_nontemporal_store(t, reinterpret_cast<i2v *>(P.uv + g));
+                    } else {
+                        P.uv[g] = make_int2(lpf_sat_i32(ru), lpf_sat_i32(rv));
+                    }
+                }
                 if (P.depth) P.depth[g] = d;
                 if (P.uf) P.uf[g] = uf;
                 if (P.vf) P.vf[g] = vf;
             }
-            const unsigned long long vb = __ballot(valid);
-            const unsigned long long mb = __ballot(lab != 0);
-            if (lane == 0) {
-                const size_t row = (size_t)sid * rows_per_seg + ((c - seg_start) >> 6) + r * 4 + wave;
-                P.vbal[row] = vb;
-                P.mbal[row] = mb;
+        }
+        unsigned long long myv = 0, mym = 0;                // lane r keeps the ballots of row r
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int idx = wbase + r * 64;
+            uint32_t l = lab[r];
+            if (idx < seg_end && !(FL & LPF_F_LAB_NOSTORE)) {
+                if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + fr.pt_off + idx);
+                else P.label_bits[fr.pt_off + idx] = l;
             }
+            const unsigned long long vb = __ballot(valid[r]);
+            const unsigned long long mb = __ballot(l != 0);
+            if (lane == r) { myv = vb; mym = mb; }
             nvalid_w += __popcll(vb);
             nmask_w += __popcll(mb);
-            while (lab) {                                   // rare: per-instance counts
-                const int m = __ffs(lab) - 1;
-                lab &= lab - 1;
-                atomicAdd(&s_inst[m], 1u);
+            while (l) {                                     // rare: per-instance counts
+                const int m = __ffs(l) - 1;
+                l &= l - 1;
+                atomicAdd(&s_cnt[2 + m], 1u);
             }
         }
+        if (lane < ROWS && !(FL & LPF_F_LAB_NOBAL)) {       // one contiguous 8*ROWS-byte store per array
+            const size_t row = (size_t)sid * rows_per_seg + ((c - seg_start) >> 6) + wave * ROWS + lane;
+            P.vbal[row] = myv;
+            P.mbal[row] = mym;
+        }
     }
-    if (lane == 0) { atomicAdd(&s_nvalid, nvalid_w); atomicAdd(&s_nmask, nmask_w); }
+    if (lane == 0) { atomicAdd(&s_cnt[0], nvalid_w); atomicAdd(&s_cnt[1], nmask_w); }
     __syncthreads();
-    if (tid == 0) P.seg_cnt[sid] = make_uint2(s_nvalid, s_nmask);
-    if (tid < 32) {
-        const unsigned cnt = s_inst[tid];
-        P.seg_inst[(size_t)tid * P.nseg_cap + sid] = cnt;
-        if (cnt) atomicAdd(&P.inst_total[f * 32 + tid], cnt);
+    if (!(FL & LPF_F_LAB_NOTAB)) {
+        // integer adds into the segment's counters (order-independent, so still deterministic);
+        // two 32-bit counters per 64-bit atomic: neither half can carry (each sum < 2^32)
+        if (tid < (2 + P.M + 1) >> 1) {
+            const unsigned long long v = (unsigned long long)s_cnt[2 * tid] | ((unsigned long long)s_cnt[2 * tid + 1] << 32);
+            if (v)
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.seg_tab + (size_t)(tid >> 1) * P.nseg_cap + sid) + (tid & 1), v);
+        }
     }
 }
 
+#define LPF_K1_FLAGS (LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE)
+
 // ------------------------------------------------------------------------------------
 // K6 helpers: membership of one point in one box, from precomputed box parameters
-//   oriented: boxp = { c0[3], (v[3], vv) x 3 }      (V3:187-202)
-//   aabb    : boxp = { lo[3], hi[3] }                (V3:158-162)
+//   oriented: boxp = { c0[3], (v[3], vv) x 3, -, -, -, exact_ok }   (V3:187-202)
+//   aabb    : boxp = { lo[3], hi[3] }                               (V3:158-162)
+// The reference tests t = d / vv with 0 <= t <= 1.  For a positive normal vv and a d that
+// is zero or not tiny, round-to-nearest division gives  t >= 0 <=> d >= 0  and
+// t <= 1 <=> d <= vv  (the next double above vv is >= vv*(1+2^-53), which rounds above 1),
+// so the quotient is only formed for degenerate boxes / denormal-range d.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ bool lpf_oriented_inside(double px, double py, double pz, const double *__restrict__ b)
 {
     const double rx = px - b[0], ry = py - b[1], rz = pz - b[2];
+    const bool exact_ok = b[15] != 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const double v0 = b[3 + 4 * a], v1 = b[4 + 4 * a], v2 = b[5 + 4 * a], vv = b[6 + 4 * a];
         double d = v1 * ry; d = fma(v0, rx, d); d = fma(v2, rz, d);   // dgemv_t tail order
-        const double t = d / vv;
-        if (!(t >= 0.0 && t <= 1.0)) return false;
+        bool in;
+        if (exact_ok && !(fabs(d) < 1e-250 && d != 0.0)) {
+            in = (d >= 0.0) && (d <= vv);
+        } else {
+            const double t = d / vv;
+            in = (t >= 0.0) && (t <= 1.0);
+        }
+        if (!in) return false;
     }
     return true;
 }
@@ -206,212 +313,314 @@ __device__ __forceinline__ bool lpf_aabb_inside(double px, double py, double pz,
 }
 
 // ------------------------------------------------------------------------------------
-// K2: same segmentation as K1.  Reads 2 bits per point of ballots, writes the lists.
+// SCAN: one block per frame.  Turns the per-segment counters K1 accumulated into
+//   seg_pre[g][seg] : exclusive prefix over the frame's earlier segments; for instance
+//                     counters the frame-level list offset inst_off[m] is already added, so the
+//                     value is the list position where the segment's first entry of mask m goes
+//   frame_tot[f][c] : totals of the frame
+// and leaves seg_tab zeroed for the next call (it reads every entry anyway).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments(const LpfParams P)
 {
-    __shared__ unsigned long long s_vbal[LPF_K2_ROWS], s_mbal[LPF_K2_ROWS];
-    __shared__ unsigned s_vbase[LPF_K2_ROWS], s_mbase[LPF_K2_ROWS];
-    __shared__ unsigned s_vtot, s_mtot;
-    __shared__ unsigned s_red[2][4];
-    __shared__ long long s_instpos[32];     // next write position of instance m (frame-relative)
-    __shared__ unsigned s_lidx[LPF_K2_BATCH], s_llab[LPF_K2_BATCH];
-
-    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const int sid = blockIdx.x;
-    const int f = lpf_find_frame(P.frames, P.F, sid);
-    const LpfFrame fr = P.frames[f];
-    const int seg_start = (sid - fr.seg_off) * P.seg_pts;
-    const int seg_end = min(seg_start + P.seg_pts, fr.N);
-    const int rows_per_seg = P.seg_pts >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint2 mine = P.seg_cnt[sid];
-    if (mine.x == 0) return;                               // no valid point => no masked point either
-
-    // (1) exclusive prefix of {n_valid, n_masked} over the frame's earlier segments
-    unsigned pv = 0;
-    for (int s = fr.seg_off + tid; s < sid; s += LPF_BLOCK) pv += P.seg_cnt[s].x;
+    // thread t owns the 4 consecutive segments 4t..4t+3 of a 1024-segment sweep: one 64-byte
+    // run per group, all groups loaded before the first use (one memory round trip per sweep)
+    __shared__ unsigned s_wsum[4][LPF_TAB_ROWS], s_carry[LPF_TAB_ROWS], s_tot[LPF_TAB_ROWS];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const int seg_lo = fr.seg_off, seg_hi = fr.seg_off + fr.nseg;
+    const int ngroups = (2 + P.M + 3) >> 2;
+    if (tid < LPF_TAB_ROWS) { s_tot[tid] = 0; s_carry[tid] = 0; }
+    __syncthreads();
+    // pass 1: totals (needed first: the instance prefixes start at inst_off[m])
+    for (int g = 0; g < ngroups; ++g) {
+        const uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
+        unsigned tot[4] = {0, 0, 0, 0};
+        for (int s0 = seg_lo + tid; s0 < seg_hi; s0 += 4 * LPF_BLOCK) {
+            uint4 q[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o);
-    if (lane == 0) s_red[0][wave] = pv;
-
-    // (2) per-instance: list offset inside the frame + count in earlier segments
-    const bool do_inst = (mine.y > 0) && (P.inst_idx != nullptr);
-    if (do_inst) {
-        for (int m = wave; m < P.M; m += 4) {
-            unsigned acc = 0;
-            const unsigned *__restrict__ col = P.seg_inst + (size_t)m * P.nseg_cap;
-            for (int s = fr.seg_off + lane; s < sid; s += 64) acc += col[s];
-            unsigned before = (lane < m) ? P.inst_total[f * 32 + lane] : 0u;   // inst_off[m]
+            for (int k = 0; k < 4; ++k) q[k] = row[min(s0 + k * LPF_BLOCK, seg_hi - 1)];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o); before += __shfl_down(before, o); }
-            if (lane == 0) s_instpos[m] = (long long)before + (long long)acc;
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k * LPF_BLOCK < seg_hi) { tot[0] += q[k].x; tot[1] += q[k].y; tot[2] += q[k].z; tot[3] += q[k].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot[j] += __shfl_down(tot[j], o);
+            if (lane == 0) atomicAdd(&s_tot[4 * g + j], tot[j]);
         }
     }
     __syncthreads();
-    long long run_v = (long long)s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-
-    const float4 *__restrict__ pts = P.pts + fr.pt_off;
-    const int B = fr.B;
-    const bool do_box = (mine.y > 0) && (B > 0) && (P.M > 0);
-
-    for (int b0 = seg_start; b0 < seg_end; b0 += LPF_K2_BATCH) {
-        const int nrows = min(LPF_K2_ROWS, (seg_end - b0 + 63) >> 6);
-        if (tid < LPF_K2_ROWS) {                           // == wave 0
-            const size_t row = (size_t)sid * rows_per_seg + ((b0 - seg_start) >> 6) + tid;
-            const unsigned long long vb = (tid < nrows) ? P.vbal[row] : 0ull;
-            const unsigned long long mb = (tid < nrows) ? P.mbal[row] : 0ull;
-            s_vbal[tid] = vb; s_mbal[tid] = mb;
-            unsigned cv = __popcll(vb), cm = __popcll(mb), iv = cv, im = cm;
+    if (tid < LPF_TAB_ROWS) {
+        unsigned off = 0;                                  // inst_off[m] for the instance counters
+        for (int c = 2; c < tid; ++c) off += s_tot[c];
+        s_carry[tid] = off;
+        P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = s_tot[tid];
+    }
+    __syncthreads();
+    // pass 2: exclusive prefixes, 1024 segments per sweep
+    for (int s0 = seg_lo; s0 < seg_hi; s0 += 4 * LPF_BLOCK) {
+        const int sb = s0 + 4 * tid;
+        for (int g = 0; g < ngroups; ++g) {
+            uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
+            uint4 *__restrict__ pre = P.seg_pre + (size_t)g * P.nseg_cap;
+            uint4 q[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {             // inclusive wave scan over the 64 rows
-                const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
-                if (lane >= o) { iv += tv; im += tm; }
+            for (int k = 0; k < 4; ++k) q[k] = (sb + k < seg_hi) ? row[sb + k] : make_uint4(0u, 0u, 0u, 0u);
+            unsigned loc[4][4], sum[4];                    // [k][component]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned v[4] = {j == 0 ? q[0].x : j == 1 ? q[0].y : j == 2 ? q[0].z : q[0].w,
+                                       j == 0 ? q[1].x : j == 1 ? q[1].y : j == 2 ? q[1].z : q[1].w,
+                                       j == 0 ? q[2].x : j == 1 ? q[2].y : j == 2 ? q[2].z : q[2].w,
+                                       j == 0 ? q[3].x : j == 1 ? q[3].y : j == 2 ? q[3].z : q[3].w};
+                loc[0][j] = 0; loc[1][j] = v[0]; loc[2][j] = v[0] + v[1]; loc[3][j] = v[0] + v[1] + v[2];
+                unsigned x = loc[3][j] + v[3];
+                const unsigned mine = x;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(x, o);
+                    if (lane >= o) x += t;
+                }
+                sum[j] = x - mine;                          // exclusive over the lanes of this wave
+                if (lane == 63) s_wsum[wave][4 * g + j] = x;
             }
-            s_vbase[tid] = iv - cv; s_mbase[tid] = im - cm;
-            if (tid == 63) { s_vtot = iv; s_mtot = im; }
-        }
-        __syncthreads();
-        const unsigned L = s_mtot;
-        // valid_idx: ascending by construction (rows in order, lanes in order)
-        if (P.valid_idx) {
-            for (int row = wave; row < nrows; row += 4) {
-                const unsigned long long bal = s_vbal[row];
-                if ((bal >> lane) & 1ull)
-                    P.valid_idx[fr.pt_off + run_v + s_vbase[row] + __popcll(bal & lt)] =
-                        (long long)(b0 + row * 64 + lane);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned wo = s_carry[4 * g + j];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) if (w < wave) wo += s_wsum[w][4 * g + j];
+                sum[j] += wo;
             }
-        }
-        if (L > 0 && (do_inst || do_box)) {
-            // masked points of this batch -> LDS list, same stable order
-            for (int row = wave; row < nrows; row += 4) {
-                const unsigned long long bal = s_mbal[row];
-                if ((bal >> lane) & 1ull) {
-                    const unsigned pos = s_mbase[row] + __popcll(bal & lt);
-                    const unsigned idx = (unsigned)(b0 + row * 64 + lane);
-                    s_lidx[pos] = idx;
-                    s_llab[pos] = P.label_bits[fr.pt_off + idx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (sb + k < seg_hi) {
+                    pre[sb + k] = make_uint4(sum[0] + loc[k][0], sum[1] + loc[k][1], sum[2] + loc[k][2], sum[3] + loc[k][3]);
+                    row[sb + k] = make_uint4(0u, 0u, 0u, 0u);   // self-clean for the next call
                 }
             }
             __syncthreads();
-            if (do_inst) {                                 // K5: split by instance, one wave per mask
-                for (int m = wave; m < P.M; m += 4) {
-                    long long pos = s_instpos[m];
-                    for (unsigned e0 = 0; e0 < L; e0 += 64) {
-                        const unsigned e = e0 + lane;
-                        const bool hit = (e < L) && ((s_llab[e] >> m) & 1u);
-                        const unsigned long long bal = __ballot(hit);
-                        if (hit) {
-                            const long long w = pos + __popcll(bal & lt);
-                            if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = (long long)s_lidx[e];
-                        }
-                        pos += __popcll(bal);
-                    }
-                    if (lane == 0) s_instpos[m] = pos;
+            if (tid < 4) s_carry[4 * g + tid] += s_wsum[0][4 * g + tid] + s_wsum[1][4 * g + tid] + s_wsum[2][4 * g + tid] + s_wsum[3][4 * g + tid];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: one WAVE = one segment of LPF_SEG_QUANTUM (2048) points = 32 ballot rows; four
+// independent waves per block, no block barriers.  Memory round trips on a wave's critical
+// path: {segment record, ballots, prefixes} -> {labels + xyz of the masked points, box
+// bounds} -> stores / atomics.
+// ------------------------------------------------------------------------------------
+#define LPF_K2_ROWS (LPF_SEG_QUANTUM / 64)
+#define LPF_K2_WAVES 4
+
+__device__ __forceinline__ unsigned lpf_rl(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float lpf_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ unsigned long long lpf_rl64(unsigned long long v, int l)
+{
+    return (unsigned long long)lpf_rl((unsigned)v, l) | ((unsigned long long)lpf_rl((unsigned)(v >> 32), l) << 32);
+}
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
+{
+    __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // masked points, segment-relative
+    const int lane = lpf_lane(), wave = lpf_wave();
+    const int sid = blockIdx.x * LPF_K2_WAVES + wave;
+    if (sid >= P.nseg_total) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // ---- round trip 1: everything that only depends on sid -------------------------------
+    const LpfFrame fr = (P.F > 1) ? P.segs[sid] : P.frame0;
+    const int ngroups = (2 + P.M + 3) >> 2;
+    unsigned long long vb = 0, mb = 0;
+    uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < LPF_K2_ROWS) {
+        vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
+        mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
+    }
+    if (lane < ngroups) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
+
+    const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
+    const int seg_end = min(seg_start + LPF_SEG_QUANTUM, fr.N);
+    const int nrows = (seg_end - seg_start + 63) >> 6;
+    if (lane >= nrows) { vb = 0; mb = 0; }                 // rows K1 never wrote
+    const unsigned cv = __popcll(vb), cm = __popcll(mb);
+    unsigned iv = cv, im = cm;
+#pragma unroll
+    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {            // inclusive scan over the 32 row counts
+        const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
+        if (lane >= o) { iv += tv; im += tm; }
+    }
+    const unsigned vbase = iv - cv, mbase = im - cm;
+    const unsigned nv = lpf_rl(iv, LPF_K2_ROWS - 1), L = lpf_rl(im, LPF_K2_ROWS - 1);
+    const long long run_v = (long long)lpf_rl(pre4.x, 0);
+
+    // ---- valid_idx: ascending by construction (rows in order, lanes in order) ------------
+    if (P.valid_idx && nv) {
+        long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
+        for (int row = 0; row < nrows; ++row) {
+            const unsigned long long bal = lpf_rl64(vb, row);
+            if (!bal) continue;
+            const unsigned base = lpf_rl(vbase, row);
+            if ((bal >> lane) & 1ull) dst[base + __popcll(bal & lt)] = (long long)(seg_start + row * 64 + lane);
+        }
+    }
+    const int B = fr.B;
+    const bool do_inst = P.inst_idx != nullptr;
+    const bool do_box = (B > 0) && (P.M > 0);
+    if (L == 0 || !(do_inst || do_box)) return;
+
+    // ---- masked points of the segment -> this wave's LDS list, same stable order -----------
+    unsigned short *lst = s_lidx[wave];
+    for (int row = 0; row < nrows; ++row) {
+        const unsigned long long bal = lpf_rl64(mb, row);
+        if (!bal) continue;
+        const unsigned base = lpf_rl(mbase, row);
+        if ((bal >> lane) & 1ull) lst[base + __popcll(bal & lt)] = (unsigned short)(row * 64 + lane);
+    }
+    __builtin_amdgcn_wave_barrier();                       // same wave, in-order LDS queue: reads below see the writes
+
+    // lane m keeps the next list position of mask m (the scan already added inst_off[m])
+    unsigned posreg;
+    {
+        const int c = 2 + lane, g = min(c >> 2, LPF_TAB_GROUPS - 1);
+        const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
+        posreg = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
+    }
+    const float4 *__restrict__ pts = P.pts + fr.pt_off;
+    const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
+    const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
+    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+
+    for (unsigned e0 = 0; e0 < L; e0 += 64) {
+        // ---- round trip 2: labels + xyz of up to 64 masked points, box bounds in lanes ---------
+        const unsigned e = e0 + lane;
+        const bool act = e < L;
+        const unsigned idx = (unsigned)seg_start + (unsigned)lst[act ? e : 0];
+        const unsigned lab = act ? P.label_bits[fr.pt_off + idx] : 0u;
+        float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (do_box && act) pq = pts[idx];
+        float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
+        if (do_box && lane < B) { blo = boxq[2 * lane]; bhi = boxq[2 * lane + 1]; }
+
+        // ---- K5: split by instance; ballot order == ascending point index --------------------
+        if (do_inst) {
+            for (int m = 0; m < P.M; ++m) {
+                const bool hit = (lab >> m) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (!bal) continue;
+                const long long base = (long long)lpf_rl(posreg, m);
+                if (hit) {
+                    const long long w = base + __popcll(bal & lt);
+                    if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = (long long)idx;
                 }
+                if (lane == m) posreg += (unsigned)__popcll(bal);
             }
-            if (do_box) {                                  // K6: dense over masked points, boxes uniform
-                const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-                unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-                for (unsigned e = tid; e < L; e += LPF_BLOCK) {
-                    const float4 q = pts[s_lidx[e]];
-                    const unsigned lab = s_llab[e];
-                    const double px = (double)q.x, py = (double)q.y, pz = (double)q.z;
-                    for (int b = 0; b < B; ++b) {
-                        const double *bp = boxp + (size_t)b * 16;
-                        const bool in = P.oriented ? lpf_oriented_inside(px, py, pz, bp)
-                                                   : lpf_aabb_inside(px, py, pz, bp);
+        }
+        // ---- K6: lane = masked point, uniform loop over the frame's boxes ----------------------
+        if (do_box) {
+            for (int b0 = 0; b0 < B; b0 += 64) {
+                const int nb = min(B - b0, 64);
+                if (b0 > 0) {                               // B > 64: next 64 boxes' bounds into the lanes
+                    blo = bhi = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < nb) { blo = boxq[2 * (b0 + lane)]; bhi = boxq[2 * (b0 + lane) + 1]; }
+                }
+                for (int b = 0; b < nb; ++b) {
+                    // conservative float bounds of the accepted region reject most pairs ...
+                    const float lx = lpf_rlf(blo.x, b), ly = lpf_rlf(blo.y, b), lz = lpf_rlf(blo.z, b);
+                    const float hx = lpf_rlf(bhi.x, b), hy = lpf_rlf(bhi.y, b), hz = lpf_rlf(bhi.z, b);
+                    const bool near = act && pq.x >= lx && pq.x <= hx && pq.y >= ly && pq.y <= hy && pq.z >= lz && pq.z <= hz;
+                    if (!__any(near)) continue;
+                    if (near) {                             // ... the survivors take the reference's float64 test
+                        const double *bp = boxp + (size_t)(b0 + b) * 16;
+                        const bool in = P.oriented ? lpf_oriented_inside((double)pq.x, (double)pq.y, (double)pq.z, bp)
+                                                   : lpf_aabb_inside((double)pq.x, (double)pq.y, (double)pq.z, bp);
                         if (in) {
                             unsigned l = lab;
                             while (l) {
                                 const int m = __ffs(l) - 1;
                                 l &= l - 1;
-                                atomicAdd(&cnt[m * B + b], 1u);
+                                atomicAdd(&cnt[m * B + b0 + b], 1u);
                             }
                         }
                     }
                 }
             }
         }
-        run_v += s_vtot;
-        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------
-// K3: one block per frame.  Layout of lpf_frame_summary (include/lpf.h), in int64 words:
-//   [0] n_valid  [1] n_labelled  [2..33] inst_count  [34..66] inst_off  [67..98] best_cnt
-//   then int32: best_box[32], inst_overflow, reserved   => 99*8 + 34*4 = 928 bytes
+// K3: one block (4 waves) per frame.  Layout of lpf_frame_summary (include/lpf.h), in
+// int64 words: [0] n_valid  [1] n_labelled  [2..33] inst_count  [34..66] inst_off
+// [67..98] best_cnt, then int32: best_box[32], inst_overflow, reserved  => 928 bytes
 // ------------------------------------------------------------------------------------
 #define LPF_SUMMARY_BYTES 928
 
-__global__ __launch_bounds__(64) void lpf_k3_finalize(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const LpfFrame fr = P.frames[f];
-    unsigned long long nv = 0, nm = 0;
-    for (int s = fr.seg_off + lane; s < fr.seg_off + fr.nseg; s += 64) {
-        const uint2 c = P.seg_cnt[s];
-        nv += c.x; nm += c.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o); nm += __shfl_down(nm, o); }
-
+    const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
     const int B = fr.B, M = P.M;
+    char *base = P.summary ? (char *)P.summary + (size_t)f * LPF_SUMMARY_BYTES : nullptr;
+    long long *w = (long long *)base;
+    int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
+    const unsigned *__restrict__ tot = P.frame_tot + (size_t)f * LPF_TAB_ROWS;
+
+    // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
-    long long icount = 0, best = 0;
-    int best_idx = -1;
-    if (lane < 32) {
-        icount = (lane < M) ? (long long)P.inst_total[f * 32 + lane] : 0;
-        if (lane < M) {
-            for (int b = 0; b < B; ++b) {                  // first strict maximum, starting from 0
-                const long long c = (long long)cnt[lane * B + b];
-                if (c > best) { best = c; best_idx = b; }
-            }
+    for (int m = wave; m < M; m += 4) {
+        unsigned best = 0;
+        int best_idx = 0x7fffffff;
+        for (int b = lane; b < B; b += 64) {
+            const unsigned c = cnt[m * B + b];
+            if (c > best) { best = c; best_idx = b; }      // ascending b per lane: keeps the first
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned ob = __shfl_down(best, o);
+            const int oi = __shfl_down(best_idx, o);
+            if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+        }
+        if (lane == 0 && base) {
+            w[67 + m] = (long long)best;
+            bb[m] = best ? best_idx : -1;
         }
     }
-    long long incl = icount;                               // inclusive scan over the 32 masks
+    if (base && tid < 64) {                                // wave 0: counts, offsets, flags
+        const long long c = (lane < M) ? (long long)tot[2 + lane] : 0;
+        long long incl = c;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        const long long t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    const long long total = __shfl(incl, 31);
-    if (P.summary) {
-        char *base = (char *)P.summary + (size_t)f * LPF_SUMMARY_BYTES;
-        long long *w = (long long *)base;
-        int32_t *bb = (int32_t *)(base + 99 * 8);
+        for (int o = 1; o < 32; o <<= 1) {
+            const long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const long long total = __shfl(incl, 31);
+        if (lane < 32) {
+            w[2 + lane] = c;
+            w[35 + lane] = incl;
+            if (lane >= M) { w[67 + lane] = 0; bb[lane] = -1; }
+        }
         if (lane == 0) {
-            w[0] = (long long)nv; w[1] = (long long)nm; w[34] = 0;
+            w[0] = (long long)tot[0]; w[1] = (long long)tot[1]; w[34] = 0;
             bb[32] = (total > P.inst_cap && P.inst_idx) ? 1 : 0;
             bb[33] = 0;
-        }
-        if (lane < 32) {
-            w[2 + lane] = icount;
-            w[35 + lane] = incl;
-            w[67 + lane] = best;
-            bb[lane] = best_idx;
         }
     }
     __syncthreads();
     // hand the counters over and leave the scratch zeroed for the next call
     int32_t *out = P.count_out ? P.count_out + (size_t)M * fr.box_off : nullptr;
-    for (int i = lane; i < M * B; i += 64) {
+    for (int i = tid; i < M * B; i += LPF_BLOCK) {
         if (out) out[i] = (int32_t)cnt[i];
         cnt[i] = 0;
     }
-    if (lane < 32) P.inst_total[f * 32 + lane] = 0;
 }
 
 // ------------------------------------------------------------------------------------
-// K8: masks -> label image.  64x16 output tile per block, (64+2)x(16+2) LDS tile of
-// packed membership bits; erosion = AND of the plus-shaped neighbourhood, pixels outside
-// the image read as all-ones (OpenCV erode border).
+// K8: masks -> label image.
 //   MODE 0: uint8, nonzero.  MODE 1: float, astype(uint8) != 0.  MODE 2: float, (x*255) -> u8 == 255.
 // ------------------------------------------------------------------------------------
-#define LPF_TW 64
-#define LPF_TH 16
-
 __device__ __forceinline__ unsigned lpf_f32_to_u8(float v)
 {
     int t;
@@ -426,6 +635,69 @@ __device__ __forceinline__ bool lpf_member(T v)
     if (MODE == 1) return lpf_f32_to_u8((float)v) != 0u;
     return lpf_f32_to_u8((float)v * 255.0f) == 255u;
 }
+
+// Streaming pack, 16 pixels per lane: uint8 masks are read 16 bytes per lane per mask
+// (float masks 4 x 16 bytes), the packed labels leave as four 16-byte stores.
+// Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).
+template <typename T, int MODE>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, uint32_t *__restrict__ label,
+                                                        int M, long long hw, long long total16)
+{
+    const long long g = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;    // group of 16 pixels, over all frames
+    if (g >= total16) return;
+    const long long per_frame = hw >> 4;
+    const long long f = g / per_frame, o = (g - f * per_frame) << 4;
+    const T *__restrict__ mf = masks + (size_t)f * M * hw + o;
+    uint32_t bits[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bits[i] = 0;
+    if (sizeof(T) == 1) {
+        for (int m0 = 0; m0 < M; m0 += 8) {                 // eight independent 16-byte loads in flight
+            uint4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const uint4 *>(mf + (size_t)min(m0 + j, M - 1) * hw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (m0 + j < M) {
+                    const unsigned wv[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        bits[i] |= (((wv[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 0u ? 1u : 0u) << (m0 + j);
+                }
+            }
+        }
+    } else {
+        for (int m0 = 0; m0 < M; m0 += 2) {
+            float4 q[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    q[j][k] = *reinterpret_cast<const float4 *>(mf + (size_t)min(m0 + j, M - 1) * hw + 4 * k);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (m0 + j < M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bits[4 * k + 0] |= (lpf_member<float, MODE>(q[j][k].x) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 1] |= (lpf_member<float, MODE>(q[j][k].y) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 2] |= (lpf_member<float, MODE>(q[j][k].z) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 3] |= (lpf_member<float, MODE>(q[j][k].w) ? 1u : 0u) << (m0 + j);
+                    }
+                }
+            }
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(label + (size_t)f * hw + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = make_uint4(bits[4 * k], bits[4 * k + 1], bits[4 * k + 2], bits[4 * k + 3]);
+}
+
+// General-shape pack with optional fused first erosion: 64x16 output tile per block,
+// (64+2)x(16+2) LDS tile of packed membership bits; erosion = AND of the plus-shaped
+// neighbourhood, pixels outside the image read as all-ones (OpenCV erode border).
+#define LPF_TW 64
+#define LPF_TH 16
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict__ masks, uint32_t *__restrict__ label,
@@ -460,7 +732,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict_
     }
 }
 
-// further erosion iterations on the packed image (all 32 masks per AND)
+// erosion iterations on the packed image (all 32 masks per AND), LDS-staged tile
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_erode_packed(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                               int H, int W)
 {

@@ -1,0 +1,64 @@
+"""The reference's NumPy statements for K1-K7, as one function (TEST / BASELINE ONLY).
+
+This is what the reference executes per frame on the host (V3:565-569, 584-592,
+211-233, 167-204, 344-379 -- paths relative to /root/reference/Coding_testes),
+restated with the same array expressions and dtypes so that its wall time is the
+"reference NumPy path" of BASELINE.md (B0).  cv2.resize is the identity at equal size
+(masks are H x W), so it is omitted.  Only tests/ and bench.py's cpu_baseline leg
+import this module.
+"""
+import numpy as np
+
+
+def cam2image(K3, points):
+    """kitti360scripts CameraPerspective.cam2image on f64 [3,N]."""
+    proj = np.matmul(K3.reshape(1, 3, 3), points[None])
+    depth = proj[:, 2, :]
+    depth[depth == 0] = -1e-6
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        u = np.round(proj[:, 0, :] / np.abs(depth)).astype(int)
+        v = np.round(proj[:, 1, :] / np.abs(depth)).astype(int)
+    return u[0], v[0], depth[0]
+
+
+def oriented_point_in_bbox(points, c):
+    if len(points) == 0:
+        return np.array([])
+    v1, v2, v3 = c[1] - c[0], c[3] - c[0], c[4] - c[0]
+    rel = points - c[0]
+    p1 = np.dot(rel, v1) / np.dot(v1, v1)
+    p2 = np.dot(rel, v2) / np.dot(v2, v2)
+    p3 = np.dot(rel, v3) / np.dot(v3, v3)
+    return (p1 >= 0) & (p1 <= 1) & (p2 >= 0) & (p2 <= 1) & (p3 >= 0) & (p3 <= 1)
+
+
+def frame_path(points, T, K3, W, H, dmax, masks, corners_velo, min_points=10):
+    """points f32[N,4]; masks [M,H,W] (uint8 or float); corners_velo f64[B,8,3].
+    Returns (u, v, valid_indices, mask_index_lists, count_mb, best_box, best_cnt)."""
+    points_homo = points.copy()
+    points_homo[:, 3] = 1
+    pointsCam = np.matmul(T, points_homo.T).T[:, :3]
+    u, v, depth = cam2image(K3, pointsCam.T)
+    valid = (u >= 0) & (u < W) & (v >= 0) & (v < H) & (depth > 0) & (depth < dmax)
+    valid_indices = np.where(valid)[0]
+    u_valid, v_valid = u[valid], v[valid]
+    points_valid = points[valid_indices, :3]
+    lists, sets = [], []
+    for mask in masks:
+        sel = mask.astype(np.uint8)[v_valid, u_valid] > 0.5
+        lists.append(valid_indices[sel])
+        sets.append(points_valid[sel] if np.count_nonzero(sel) > 0 else np.array([]).reshape(0, 3))
+    M, B = len(masks), len(corners_velo)
+    count = np.zeros((M, B), np.int64)
+    best_box = np.full(M, -1, np.int32)
+    best_cnt = np.zeros(M, np.int64)
+    for m, car_points in enumerate(sets):
+        if len(car_points) == 0:
+            continue
+        for b in range(B):
+            inside = oriented_point_in_bbox(car_points, corners_velo[b])
+            n = int(np.sum(inside))
+            count[m, b] = n
+            if n > best_cnt[m]:
+                best_cnt[m], best_box[m] = n, b
+    return u, v, valid_indices, lists, count, best_box, best_cnt

@@ -52,7 +52,9 @@ def _compare(r, o, M, want_float=True):
         assert np.array_equal(r["best_cnt"], o["best_cnt"])
     if want_float:
         for k in ("depth", "uf", "vf"):
-            _close(r[k], o[k])
+            _close(r[k], o[k])                       # the contract: 1e-5
+            # observed on gfx950: the kernel's float64 arithmetic is bit-identical to the oracle's
+            assert np.array_equal(r[k], o[k], equal_nan=True), k
 
 
 @pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
