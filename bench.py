@@ -76,7 +76,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per cloud")
     ap.add_argument("--frames", type=int, default=8, help="clouds per step (one batched launch)")
-    ap.add_argument("--buffers", type=int, default=3, help="distinct resident batches cycled through")
+    ap.add_argument("--buffers", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (one context each) the steps alternate over; 2 overlaps the short kernels of one "
+                         "step with the streaming kernel of the next (higher points/s, longer per-kernel durations)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the second, event-bracketed pass")
@@ -129,14 +132,22 @@ def main():
                          summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev)))
     frame_off = np.arange(F + 1, dtype=np.int64) * n
 
-    ctx = LpfContext(local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_camera(T, K, W, H, 0.0, DMAX)
-    ctx.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
+    # steps alternate over `streams` contexts (own HIP stream + scratch each), so the short
+    # latency-bound kernels of one step overlap the bandwidth-bound kernel of the next
+    nstream = max(1, min(args.streams, nbuf))
+    nbuf -= nbuf % nstream                                  # buffer b always belongs to context b % nstream
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstream - 1)]
+    ctxs = []
+    for st in streams:
+        c = LpfContext(local_rank)
+        c.set_stream(st.cuda_stream)
+        c.set_camera(T, K, W, H, 0.0, DMAX)
+        c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
+        ctxs.append(c)
+    ctx = ctxs[0]
 
-    # one step = K8 mask pack (u8 masks in HBM -> label images) + K1 + K2 + K3, pre-marshalled
-    steps_fn = [ctx.make_device_step(pts_dev[b], frame_off, masks_u8=masks_dev[b], inst_cap=n, **outs[b])
+    # one step = K8 mask pack (u8 masks in HBM -> label images) + K1 + scan + K2 + K3, pre-marshalled
+    steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=masks_dev[b], inst_cap=n, **outs[b])
                 for b in range(nbuf)]
 
     def barrier():
@@ -150,6 +161,7 @@ def main():
         for i in range(k):
             steps_fn[i % nbuf]()
         if world > 1:                                               # final aggregate metrics only
+            torch.cuda.synchronize(dev)                             # all streams: the last step may be on any of them
             sm = np.frombuffer(outs[(k - 1) % nbuf]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
             agg = torch.tensor([int(sm["n_valid"].sum()), int(sm["n_labelled"].sum()), int(sm["inst_count"].sum()), F],
                                dtype=torch.int64, device=dev)
@@ -162,6 +174,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    torch.cuda.synchronize(dev)                                     # inputs were produced on torch's stream
     for i in range(args.warmup):
         steps_fn[i % nbuf]()
     torch.cuda.synchronize(dev)
@@ -169,11 +182,14 @@ def main():
 
     k1_ms, k1_n, elapsed_ev = 0.0, 0, None
     if not args.no_events:                                          # pass 2: same steps, HIP events around K1
-        ctx.profile_enable(True)
-        ctx.profile_read(reset=True)
+        for c in ctxs:
+            c.profile_enable(True)
+            c.profile_read(reset=True)
         elapsed_ev = timed(args.steps)
-        k1_ms, k1_n = ctx.profile_read(reset=True)
-        ctx.profile_enable(False)
+        for c in ctxs:
+            ms_c, n_c = c.profile_read(reset=True)
+            k1_ms, k1_n = k1_ms + ms_c, k1_n + n_c
+            c.profile_enable(False)
 
     # the numbers are only reported if the last step's results equal the CPU oracle's (frame 0, rank 0)
     if rank == 0:
@@ -211,7 +227,7 @@ def main():
                                    "masks + %d 3D boxes, V4 clip depth<30; one launch set per step produces all outputs "
                                    "(u,v,label,valid_idx,instance lists,count_mb,best box)" % (F, n, N_MASKS, N_BOXES),
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
-                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf,
+                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream,
                        "sharding": "clouds per rank, no data-path collective"},
         }
         if k1_n:
@@ -229,7 +245,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

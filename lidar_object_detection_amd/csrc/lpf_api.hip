@@ -529,10 +529,17 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
     }
-    hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
-    LPF_HIP(c, hipGetLastError());
+    {
+        int max_nseg = 0;
+        for (int f = 0; f < F; ++f) if (c->h_frames[f].nseg > max_nseg) max_nseg = c->h_frames[f].nseg;
+        if (max_nseg <= 4 * LPF_BLOCK && (2 + M + 3) / 4 <= 3)          // <= 1024 segments per frame, M <= 10
+            hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+        else
+            hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+        LPF_HIP(c, hipGetLastError());
+    }
     if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
-        hipLaunchKernelGGL(lpf_k2_lists, dim3((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES), dim3(LPF_BLOCK), 0, c->stream, P);
+        hipLaunchKernelGGL((lpf_k2_lists), dim3((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES), dim3(LPF_BLOCK), 0, c->stream, P);
         LPF_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);

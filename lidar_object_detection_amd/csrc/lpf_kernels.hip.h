@@ -320,89 +320,124 @@ __device__ __forceinline__ bool lpf_aabb_inside(double px, double py, double pz,
 //   frame_tot[f][c] : totals of the frame
 // and leaves seg_tab zeroed for the next call (it reads every entry anyway).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments(const LpfParams P)
+// block-wide exclusive offsets of per-thread sums (4 components); also returns the totals
+__device__ __forceinline__ void lpf_block_excl4(const unsigned sum[4], unsigned excl[4], unsigned all[4],
+                                                unsigned (*s_wsum)[4], int lane, int wave)
 {
-    // thread t owns the 4 consecutive segments 4t..4t+3 of a 1024-segment sweep: one 64-byte
-    // run per group, all groups loaded before the first use (one memory round trip per sweep)
-    __shared__ unsigned s_wsum[4][LPF_TAB_ROWS], s_carry[LPF_TAB_ROWS], s_tot[LPF_TAB_ROWS];
+    unsigned inc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned x = sum[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(x, o);
+            if (lane >= o) x += t;
+        }
+        inc[j] = x;
+        if (lane == 63) s_wsum[wave][j] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned wo = 0, a = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned t = s_wsum[w][j]; if (w < wave) wo += t; a += t; }
+        excl[j] = wo + inc[j] - sum[j];
+        all[j] = a;
+    }
+    __syncthreads();
+}
+
+template <int NG>   // NG > 0: at most NG groups and 1024 segments -> everything stays in registers
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments_t(const LpfParams P)
+{
+    // thread t owns the contiguous run of R = ceil(nseg/256) segments starting at t*R.
+    __shared__ unsigned s_toff[NG > 0 ? 1 : LPF_TAB_GROUPS][LPF_BLOCK][4];
+    __shared__ unsigned s_wsum[4][4], s_tot[LPF_TAB_ROWS], s_off[LPF_TAB_ROWS];
     const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
     const int seg_lo = fr.seg_off, seg_hi = fr.seg_off + fr.nseg;
     const int ngroups = (2 + P.M + 3) >> 2;
-    if (tid < LPF_TAB_ROWS) { s_tot[tid] = 0; s_carry[tid] = 0; }
-    __syncthreads();
-    // pass 1: totals (needed first: the instance prefixes start at inst_off[m])
-    for (int g = 0; g < ngroups; ++g) {
-        const uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
-        unsigned tot[4] = {0, 0, 0, 0};
-        for (int s0 = seg_lo + tid; s0 < seg_hi; s0 += 4 * LPF_BLOCK) {
-            uint4 q[4];
+    const int R = (NG > 0) ? 4 : (fr.nseg + LPF_BLOCK - 1) / LPF_BLOCK;
+    const int my_lo = min(seg_lo + tid * R, seg_hi), my_hi = min(my_lo + R, seg_hi);
+
+    if (NG > 0) {
+        // ---- one memory round trip: all runs of all groups are loaded before the first use ----
+        constexpr int G = NG > 0 ? NG : 1;
+        uint4 q[G][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = row[min(s0 + k * LPF_BLOCK, seg_hi - 1)];
+        for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (s0 + k * LPF_BLOCK < seg_hi) { tot[0] += q[k].x; tot[1] += q[k].y; tot[2] += q[k].z; tot[3] += q[k].w; }
-        }
+                q[g][k] = (g < ngroups && my_lo + k < my_hi) ? P.seg_tab[(size_t)g * P.nseg_cap + my_lo + k] : make_uint4(0u, 0u, 0u, 0u);
+        unsigned excl[G][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) tot[j] += __shfl_down(tot[j], o);
-            if (lane == 0) atomicAdd(&s_tot[4 * g + j], tot[j]);
+        for (int g = 0; g < G; ++g) {
+            const unsigned sum[4] = {q[g][0].x + q[g][1].x + q[g][2].x + q[g][3].x, q[g][0].y + q[g][1].y + q[g][2].y + q[g][3].y,
+                                     q[g][0].z + q[g][1].z + q[g][2].z + q[g][3].z, q[g][0].w + q[g][1].w + q[g][2].w + q[g][3].w};
+            unsigned all[4];
+            lpf_block_excl4(sum, excl[g], all, s_wsum, lane, wave);
+            if (tid == 0) { s_tot[4 * g] = all[0]; s_tot[4 * g + 1] = all[1]; s_tot[4 * g + 2] = all[2]; s_tot[4 * g + 3] = all[3]; }
         }
+        __syncthreads();
+        if (tid < LPF_TAB_ROWS) {
+            const bool used = tid < 4 * ngroups;
+            unsigned off = 0;                              // inst_off[m] for the instance counters
+            if (used) for (int c = 2; c < tid; ++c) off += s_tot[c];
+            s_off[tid] = off;
+            P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = used ? s_tot[tid] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ngroups) break;
+            unsigned run[4] = {s_off[4 * g] + excl[g][0], s_off[4 * g + 1] + excl[g][1], s_off[4 * g + 2] + excl[g][2], s_off[4 * g + 3] + excl[g][3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (my_lo + k < my_hi) {
+                    P.seg_pre[(size_t)g * P.nseg_cap + my_lo + k] = make_uint4(run[0], run[1], run[2], run[3]);
+                    P.seg_tab[(size_t)g * P.nseg_cap + my_lo + k] = make_uint4(0u, 0u, 0u, 0u);   // self-clean
+                }
+                run[0] += q[g][k].x; run[1] += q[g][k].y; run[2] += q[g][k].z; run[3] += q[g][k].w;
+            }
+        }
+        return;
+    }
+    // ---- general shape: phase 1 sums each run, phase 2 re-reads the runs (L2-hot) ------------
+    for (int g = 0; g < ngroups; ++g) {
+        const uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
+        unsigned sum[4] = {0, 0, 0, 0};
+#pragma unroll 8
+        for (int sg = my_lo; sg < my_hi; ++sg) {
+            const uint4 v = row[sg];
+            sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        }
+        unsigned excl[4], all[4];
+        lpf_block_excl4(sum, excl, all, s_wsum, lane, wave);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_toff[NG > 0 ? 0 : g][tid][j] = excl[j]; if (tid == 0) s_tot[4 * g + j] = all[j]; }
     }
     __syncthreads();
     if (tid < LPF_TAB_ROWS) {
-        unsigned off = 0;                                  // inst_off[m] for the instance counters
-        for (int c = 2; c < tid; ++c) off += s_tot[c];
-        s_carry[tid] = off;
-        P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = s_tot[tid];
+        const bool used = tid < 4 * ngroups;
+        unsigned off = 0;
+        if (used) for (int c = 2; c < tid; ++c) off += s_tot[c];
+        s_off[tid] = off;
+        P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = used ? s_tot[tid] : 0u;
     }
     __syncthreads();
-    // pass 2: exclusive prefixes, 1024 segments per sweep
-    for (int s0 = seg_lo; s0 < seg_hi; s0 += 4 * LPF_BLOCK) {
-        const int sb = s0 + 4 * tid;
-        for (int g = 0; g < ngroups; ++g) {
-            uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
-            uint4 *__restrict__ pre = P.seg_pre + (size_t)g * P.nseg_cap;
-            uint4 q[4];
+    for (int g = 0; g < ngroups; ++g) {
+        uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
+        uint4 *__restrict__ pre = P.seg_pre + (size_t)g * P.nseg_cap;
+        unsigned run[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = (sb + k < seg_hi) ? row[sb + k] : make_uint4(0u, 0u, 0u, 0u);
-            unsigned loc[4][4], sum[4];                    // [k][component]
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned v[4] = {j == 0 ? q[0].x : j == 1 ? q[0].y : j == 2 ? q[0].z : q[0].w,
-                                       j == 0 ? q[1].x : j == 1 ? q[1].y : j == 2 ? q[1].z : q[1].w,
-                                       j == 0 ? q[2].x : j == 1 ? q[2].y : j == 2 ? q[2].z : q[2].w,
-                                       j == 0 ? q[3].x : j == 1 ? q[3].y : j == 2 ? q[3].z : q[3].w};
-                loc[0][j] = 0; loc[1][j] = v[0]; loc[2][j] = v[0] + v[1]; loc[3][j] = v[0] + v[1] + v[2];
-                unsigned x = loc[3][j] + v[3];
-                const unsigned mine = x;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned t = __shfl_up(x, o);
-                    if (lane >= o) x += t;
-                }
-                sum[j] = x - mine;                          // exclusive over the lanes of this wave
-                if (lane == 63) s_wsum[wave][4 * g + j] = x;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned wo = s_carry[4 * g + j];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) if (w < wave) wo += s_wsum[w][4 * g + j];
-                sum[j] += wo;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (sb + k < seg_hi) {
-                    pre[sb + k] = make_uint4(sum[0] + loc[k][0], sum[1] + loc[k][1], sum[2] + loc[k][2], sum[3] + loc[k][3]);
-                    row[sb + k] = make_uint4(0u, 0u, 0u, 0u);   // self-clean for the next call
-                }
-            }
-            __syncthreads();
-            if (tid < 4) s_carry[4 * g + tid] += s_wsum[0][4 * g + tid] + s_wsum[1][4 * g + tid] + s_wsum[2][4 * g + tid] + s_wsum[3][4 * g + tid];
-            __syncthreads();
+        for (int j = 0; j < 4; ++j) run[j] = s_off[4 * g + j] + s_toff[NG > 0 ? 0 : g][tid][j];
+#pragma unroll 8
+        for (int sg = my_lo; sg < my_hi; ++sg) {
+            const uint4 v = row[sg];
+            pre[sg] = make_uint4(run[0], run[1], run[2], run[3]);
+            row[sg] = make_uint4(0u, 0u, 0u, 0u);           // self-clean for the next call
+            run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
         }
     }
 }
@@ -422,10 +457,40 @@ __device__ __forceinline__ unsigned long long lpf_rl64(unsigned long long v, int
 {
     return (unsigned long long)lpf_rl((unsigned)v, l) | ((unsigned long long)lpf_rl((unsigned)(v >> 32), l) << 32);
 }
-
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
+// per-lane source lane (ds_bpermute): every lane is active at the call sites
+__device__ __forceinline__ unsigned long long lpf_rl64_var(unsigned long long v, int l)
 {
-    __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // masked points, segment-relative
+    return (unsigned long long)(unsigned)__shfl((int)(unsigned)v, l) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(v >> 32), l) << 32);
+}
+
+// Set bits of 32 ballots (lane r < 32 holds row r) -> ascending list in LDS.  Lane r walks the
+// low half of its row, lane r + 32 the high half: work is O(set bits), not O(rows x 64).
+__device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, unsigned rowbase, int lane, unsigned short *lst)
+{
+    const int r = lane & 31, hi = lane >> 5;
+    const unsigned long long bits = lpf_rl64_var(rowbits, r);
+    const unsigned base = (unsigned)__shfl((int)rowbase, r);
+    unsigned half = hi ? (unsigned)(bits >> 32) : (unsigned)bits;
+    unsigned pos = base + (hi ? __popc((unsigned)bits) : 0u);
+    const unsigned short tag = (unsigned short)(r * 64 + hi * 32);
+    while (half) {
+        const int b = __ffs(half) - 1;
+        half &= half - 1;
+        lst[pos++] = (unsigned short)(tag + b);
+    }
+}
+
+#define LPF_F2_LAB_NOVALID 1u
+#define LPF_F2_LAB_NOLIST 2u      // stop after valid_idx
+#define LPF_F2_LAB_NOBOX 4u
+#define LPF_F2_LAB_NOINST 8u
+
+template <unsigned FL2>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
+{
+    __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // valid, then masked points (segment-relative)
+    __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz of the current 64 masked points
+    __shared__ float4 s_bq[LPF_K2_WAVES][2 * 64];                      // {lo, hi} of the current <= 64 boxes
     const int lane = lpf_lane(), wave = lpf_wave();
     const int sid = blockIdx.x * LPF_K2_WAVES + wave;
     if (sid >= P.nseg_total) return;
@@ -456,29 +521,23 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
     const unsigned nv = lpf_rl(iv, LPF_K2_ROWS - 1), L = lpf_rl(im, LPF_K2_ROWS - 1);
     const long long run_v = (long long)lpf_rl(pre4.x, 0);
 
-    // ---- valid_idx: ascending by construction (rows in order, lanes in order) ------------
-    if (P.valid_idx && nv) {
+    // ---- valid_idx: ascending by construction (rows in order, lanes in order); staged in LDS so
+    //      the HBM writes are whole 512-byte runs instead of a few bytes per row ---------------
+    unsigned short *lst = s_lidx[wave];
+    if (P.valid_idx && nv && !(FL2 & LPF_F2_LAB_NOVALID)) {
+        lpf_bits_to_list(vb, vbase, lane, lst);
+        __builtin_amdgcn_wave_barrier();
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
-        for (int row = 0; row < nrows; ++row) {
-            const unsigned long long bal = lpf_rl64(vb, row);
-            if (!bal) continue;
-            const unsigned base = lpf_rl(vbase, row);
-            if ((bal >> lane) & 1ull) dst[base + __popcll(bal & lt)] = (long long)(seg_start + row * 64 + lane);
-        }
+        for (unsigned e = lane; e < nv; e += 64) dst[e] = (long long)(seg_start + (int)lst[e]);
+        __builtin_amdgcn_wave_barrier();                   // the list is reused for the masked points
     }
     const int B = fr.B;
-    const bool do_inst = P.inst_idx != nullptr;
-    const bool do_box = (B > 0) && (P.M > 0);
-    if (L == 0 || !(do_inst || do_box)) return;
+    const bool do_inst = (P.inst_idx != nullptr) && !(FL2 & LPF_F2_LAB_NOINST);
+    const bool do_box = (B > 0) && (P.M > 0) && !(FL2 & LPF_F2_LAB_NOBOX);
+    if (L == 0 || !(do_inst || do_box) || (FL2 & LPF_F2_LAB_NOLIST)) return;
 
     // ---- masked points of the segment -> this wave's LDS list, same stable order -----------
-    unsigned short *lst = s_lidx[wave];
-    for (int row = 0; row < nrows; ++row) {
-        const unsigned long long bal = lpf_rl64(mb, row);
-        if (!bal) continue;
-        const unsigned base = lpf_rl(mbase, row);
-        if ((bal >> lane) & 1ull) lst[base + __popcll(bal & lt)] = (unsigned short)(row * 64 + lane);
-    }
+    lpf_bits_to_list(mb, mbase, lane, lst);
     __builtin_amdgcn_wave_barrier();                       // same wave, in-order LDS queue: reads below see the writes
 
     // lane m keeps the next list position of mask m (the scan already added inst_off[m])
@@ -518,30 +577,40 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
                 if (lane == m) posreg += (unsigned)__popcll(bal);
             }
         }
-        // ---- K6: lane = masked point, uniform loop over the frame's boxes ----------------------
+        // ---- K6: (masked point, box) pairs spread over the lanes: 64 points x <= 64 boxes per
+        //      round, both sides staged in this wave's LDS; a conservative float AABB of the
+        //      accepted region rejects most pairs, the survivors take the reference's f64 test ----
         if (do_box) {
+            const int nact = min(64, (int)(L - e0));
+            __builtin_amdgcn_wave_barrier();
+            s_pt[wave][lane] = make_float4(pq.x, pq.y, pq.z, __uint_as_float(lab));   // .w carries the label bits
             for (int b0 = 0; b0 < B; b0 += 64) {
                 const int nb = min(B - b0, 64);
-                if (b0 > 0) {                               // B > 64: next 64 boxes' bounds into the lanes
+                if (b0 > 0) {                               // B > 64: next 64 boxes' bounds
                     blo = bhi = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (lane < nb) { blo = boxq[2 * (b0 + lane)]; bhi = boxq[2 * (b0 + lane) + 1]; }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                for (int b = 0; b < nb; ++b) {
-                    // conservative float bounds of the accepted region reject most pairs ...
-                    const float lx = lpf_rlf(blo.x, b), ly = lpf_rlf(blo.y, b), lz = lpf_rlf(blo.z, b);
-                    const float hx = lpf_rlf(bhi.x, b), hy = lpf_rlf(bhi.y, b), hz = lpf_rlf(bhi.z, b);
-                    const bool near = act && pq.x >= lx && pq.x <= hx && pq.y >= ly && pq.y <= hy && pq.z >= lz && pq.z <= hz;
-                    if (!__any(near)) continue;
-                    if (near) {                             // ... the survivors take the reference's float64 test
-                        const double *bp = boxp + (size_t)(b0 + b) * 16;
-                        const bool in = P.oriented ? lpf_oriented_inside((double)pq.x, (double)pq.y, (double)pq.z, bp)
-                                                   : lpf_aabb_inside((double)pq.x, (double)pq.y, (double)pq.z, bp);
-                        if (in) {
-                            unsigned l = lab;
-                            while (l) {
-                                const int m = __ffs(l) - 1;
-                                l &= l - 1;
-                                atomicAdd(&cnt[m * B + b0 + b], 1u);
+                s_bq[wave][2 * lane] = blo; s_bq[wave][2 * lane + 1] = bhi;
+                __builtin_amdgcn_wave_barrier();
+                int sh = 0;                                 // boxes padded to a power of two: pair -> (point, box) by shift/mask
+                while ((1 << sh) < nb) ++sh;
+                const int npair = nact << sh;
+                for (int p0 = 0; p0 < npair; p0 += 64) {
+                    const int p = p0 + lane, e = p >> sh, b = p & ((1 << sh) - 1);
+                    if (p < npair && b < nb) {
+                        const float4 x = s_pt[wave][e], lo = s_bq[wave][2 * b], hi = s_bq[wave][2 * b + 1];
+                        if (x.x >= lo.x && x.x <= hi.x && x.y >= lo.y && x.y <= hi.y && x.z >= lo.z && x.z <= hi.z) {
+                            const double *bp = boxp + (size_t)(b0 + b) * 16;
+                            const bool in = P.oriented ? lpf_oriented_inside((double)x.x, (double)x.y, (double)x.z, bp)
+                                                       : lpf_aabb_inside((double)x.x, (double)x.y, (double)x.z, bp);
+                            if (in) {
+                                unsigned l = __float_as_uint(x.w);
+                                while (l) {
+                                    const int m = __ffs(l) - 1;
+                                    l &= l - 1;
+                                    atomicAdd(&cnt[m * B + b0 + b], 1u);
+                                }
                             }
                         }
                     }
@@ -550,6 +619,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists(const LpfParams P)
         }
     }
 }
+
+#define lpf_k2_lists lpf_k2_lists_t<0u>
 
 // ------------------------------------------------------------------------------------
 // K3: one block (4 waves) per frame.  Layout of lpf_frame_summary (include/lpf.h), in

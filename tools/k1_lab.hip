@@ -90,15 +90,8 @@ int main(int argc, char **argv)
 
     const unsigned BEST = LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE;
     const Variant vars[] = {
-        {"r8  x4 nt", launch_t<8, BEST>, 8},
         {"r4  x4 nt", launch_t<4, BEST>, 4},
-        {"r4  x4 nt NOTAB", launch_t<4, BEST | LPF_F_LAB_NOTAB>, 4},
-        {"r4  x4 nt NOMATH NOGATHER", launch_t<4, BEST | LPF_F_LAB_NOMATH | LPF_F_LAB_NOGATHER>, 4},
         {"r2  x4 nt", launch_t<2, BEST>, 2},
-        {"r2  x4 nt NOTAB", launch_t<2, BEST | LPF_F_LAB_NOTAB>, 2},
-        {"r2  x4 nt NOGATHER", launch_t<2, BEST | LPF_F_LAB_NOGATHER>, 2},
-        {"r2  x4 nt NOMATH NOGATHER", launch_t<2, BEST | LPF_F_LAB_NOMATH | LPF_F_LAB_NOGATHER>, 2},
-        {"r1  x4 nt", launch_t<1, BEST>, 1},
     };
     {   // reference kernels
         float4 *o4; CK(hipMalloc(&o4, (size_t)N * 16));
@@ -122,7 +115,52 @@ int main(int argc, char **argv)
         timeit("ref copy16->8+4 r8", [&](int b) { hipLaunchKernelGGL(ref_copy_16_8_4<8>, dim3(nb8), dim3(256), 0, s, pts[b], uv[b], lab[b], N); }, 28.0 * N);
         CK(hipFree(o4));
     }
-    const int segmul[] = {1, 4};
+    {   // ---- K2 / scan ablations on a real K1 result (F = 1) ----
+        const int seg_pts = LPF_SEG_QUANTUM, nseg = (N + seg_pts - 1) / seg_pts;
+        LpfFrame fr; memset(&fr, 0, sizeof fr); fr.N = N; fr.nseg = nseg; fr.B = 32;
+        uint4 *pre; unsigned *ftot, *cnt; long long *vidx, *iidx; double *boxp; float *boxq;
+        CK(hipMalloc(&pre, LPF_TAB_GROUPS * maxseg * 16)); CK(hipMalloc(&ftot, LPF_TAB_ROWS * 4)); CK(hipMalloc(&cnt, 8 * 32 * 4));
+        CK(hipMemset(cnt, 0, 8 * 32 * 4));
+        CK(hipMalloc(&vidx, (size_t)N * 8)); CK(hipMalloc(&iidx, (size_t)N * 8));
+        std::vector<double> hbp(32 * 16, 0.0); std::vector<float> hbq(32 * 8, 0.f);
+        for (int b = 0; b < 32; ++b) {   // axis-aligned 4 m cubes in front of the sensor
+            double *o = &hbp[b * 16]; const double cx = 5 + (b % 8) * 5, cy = -20 + (b / 8) * 10, cz = -2;
+            o[0] = cx; o[1] = cy; o[2] = cz; o[3] = 4; o[6] = 16; o[8] = 4; o[10] = 16; o[13] = 4; o[14] = 16; o[15] = 1;
+            float *q = &hbq[b * 8]; q[0] = cx - 0.1f; q[1] = cy - 0.1f; q[2] = cz - 0.1f; q[4] = cx + 4.1f; q[5] = cy + 4.1f; q[6] = cz + 4.1f;
+        }
+        CK(hipMalloc(&boxp, hbp.size() * 8)); CK(hipMalloc(&boxq, hbq.size() * 4));
+        CK(hipMemcpy(boxp, hbp.data(), hbp.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(boxq, hbq.data(), hbq.size() * 4, hipMemcpyHostToDevice));
+        P.seg_pts = seg_pts; P.nseg_total = nseg; P.nseg_cap = nseg; P.frame0 = fr; P.oriented = 1;
+        P.seg_pre = pre; P.frame_tot = ftot; P.cnt = cnt; P.valid_idx = vidx; P.inst_idx = iidx; P.inst_cap = N; P.boxp = boxp; P.boxq = boxq;
+        P.pts = pts[0]; P.uv = uv[0]; P.label_bits = lab[0];
+        launch_t<4, LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE>(P, nseg, s);
+        CK(hipStreamSynchronize(s));
+        auto timeit2 = [&](const char *name, auto fn) {
+            for (int it = 0; it < 10; ++it) fn();
+            CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+            for (int it = 0; it < 100; ++it) fn();
+            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%-34s %10.2f us\n", name, 1e3 * ms / 100);
+        };
+        // the scan zeroes seg_tab: time it on the (then empty) table, structure is identical
+        if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P);
+        timeit2("scan_segments (1 frame)", [&]() { if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P); });
+        // rebuild a real prefix table for K2
+        launch_t<4, LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE>(P, nseg, s);
+        if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P);
+        CK(hipStreamSynchronize(s));
+        const int nb2 = (nseg + LPF_K2_WAVES - 1) / LPF_K2_WAVES;
+        timeit2("k2 full", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<0u>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOVALID", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOVALID>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOLIST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOVALID NOLIST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOVALID | LPF_F2_LAB_NOLIST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOBOX", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOINST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        timeit2("k2 NOBOX NOINST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
+        P.valid_idx = nullptr; P.inst_idx = nullptr; P.boxp = nullptr; P.boxq = nullptr; P.cnt = nullptr;
+    }
+    const int segmul[] = {1};
     printf("%-34s %8s %8s %10s %10s\n", "variant", "seg_pts", "blocks", "us/launch", "GB/s(28B)");
     for (const Variant &v : vars) {
         for (int sm : segmul) {
