@@ -125,6 +125,14 @@ int lpf_run(lpf_ctx *ctx, const float *pts, int64_t N, int pts_on_device, const 
 int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int F,
                   int pts_on_device, const lpf_outputs *out);
 
+/* ---- box membership as a stand-alone operator -------------------------------------------
+ * inside[b*k + i] = 1 if point i lies in box b, else 0: the boolean arrays the reference's
+ * oriented_point_in_bbox (V3:167-208, oriented = 1) and point_in_bbox (V3:143-164, oriented = 0)
+ * return, for B boxes at once.  pts: f32 [k][stride] with stride 3 or 4 (x, y, z first);
+ * corners_velo: f64 [B][8][3] host memory; pts / inside are host or device per on_device. */
+int lpf_points_in_boxes(lpf_ctx *ctx, const float *pts, int64_t k, int stride, const double *corners_velo,
+                        int B, int oriented, uint8_t *inside, int on_device);
+
 /* ---- measurement -------------------------------------------------------------------
  * With profiling on, every lpf_run* brackets its project+label kernel (lpf_k1_project, the
  * dominant kernel) with HIP events on the context's stream.  lpf_profile_read waits for the

@@ -75,6 +75,7 @@ def load():
     lib.lpf_set_boxes.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int]
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
+    lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
     lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
     lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
     _lib = lib
@@ -84,7 +85,7 @@ def load():
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
-            "lpf_profile_enable", "lpf_profile_read")
+            "lpf_points_in_boxes", "lpf_profile_enable", "lpf_profile_read")
 
 
 def _is_torch(x):
@@ -227,6 +228,19 @@ class LpfContext:
     def clear_boxes(self):
         self._check(self._lib.lpf_set_boxes(self._h, None, None, 0, 1))
         self.box_off = None
+
+    def points_in_boxes(self, points, corners, oriented=True):
+        """bool [B,k]: row b is the reference's oriented_point_in_bbox(points, corners[b]) (or point_in_bbox)."""
+        p = np.ascontiguousarray(points, dtype=np.float32)
+        if p.ndim != 2 or p.shape[1] not in (3, 4):
+            raise ValueError("points must be [k,3] or [k,4]")
+        c = np.ascontiguousarray(corners, dtype=np.float64).reshape(-1, 8, 3)
+        k, B = p.shape[0], c.shape[0]
+        out = np.zeros((B, k), np.uint8)
+        if k and B:
+            self._check(self._lib.lpf_points_in_boxes(self._h, p.ctypes.data, k, p.shape[1], c.ctypes.data, B,
+                                                      int(bool(oriented)), out.ctypes.data, 0))
+        return out.astype(bool)
 
     # -- the hot path, host arrays ------------------------------------------------------
     def run(self, points, **kw):

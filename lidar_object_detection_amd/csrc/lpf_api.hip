@@ -50,6 +50,7 @@ struct lpf_ctx {
     // per-run scratch
     DevBuf frames, segs, vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, label_scratch;
     // host-io staging
+    DevBuf pib_box, pib_pts, pib_out;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
     std::vector<LpfFrame> h_segs;
@@ -278,7 +279,7 @@ void lpf_destroy(lpf_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->frames, &c->vbal, &c->mbal,
-                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->label_scratch, &c->st_pts, &c->st_uv, &c->st_label,
+                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->label_scratch, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -573,6 +574,36 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 #undef LPF_D2H
         LPF_HIP(c, hipStreamSynchronize(c->stream));
     }
+    return LPF_OK;
+}
+
+int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, const double *corners, int B, int oriented,
+                        uint8_t *inside, int on_device)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (k < 0 || B < 0 || (stride != 3 && stride != 4) || (k > 0 && !pts) || (B > 0 && !corners) || (k > 0 && B > 0 && !inside))
+        return fail(c, LPF_ERR_ARG, "points_in_boxes: k=%lld B=%d stride=%d", (long long)k, B, stride);
+    if (k == 0 || B == 0) return LPF_OK;
+    std::vector<double> bp((size_t)B * 16);
+    std::vector<float> bq(8);
+    for (int b = 0; b < B; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data());
+    int rc;
+    if ((rc = reserve(c, c->pib_box, bp.size() * 8))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(c->pib_box.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const float *d_pts = pts;
+    uint8_t *d_out = inside;
+    if (!on_device) {
+        if ((rc = reserve(c, c->pib_pts, (size_t)k * stride * 4))) return rc;
+        if ((rc = reserve(c, c->pib_out, (size_t)k * B))) return rc;
+        LPF_HIP(c, hipMemcpyAsync(c->pib_pts.p, pts, (size_t)k * stride * 4, hipMemcpyHostToDevice, c->stream));
+        d_pts = (const float *)c->pib_pts.p; d_out = (uint8_t *)c->pib_out.p;
+    }
+    hipLaunchKernelGGL(lpf_points_in_boxes_kernel, dim3((unsigned)((k + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,
+                       d_pts, (long long)k, stride, (const double *)c->pib_box.p, B, oriented ? 1 : 0, d_out);
+    LPF_HIP(c, hipGetLastError());
+    if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));           // bp is a local
     return LPF_OK;
 }
 

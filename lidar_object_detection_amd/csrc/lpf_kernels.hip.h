@@ -689,6 +689,31 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
 }
 
 // ------------------------------------------------------------------------------------
+// Standalone K6: inside[b][i] for k points x B boxes -- the drop-in for
+// oriented_point_in_bbox / point_in_bbox (V3:143-208), which return the per-point mask.
+// Box parameters are staged in LDS 32 boxes at a time; one thread per point.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_points_in_boxes_kernel(const float *__restrict__ pts, long long k, int stride,
+                                                                        const double *__restrict__ boxp, int B, int oriented,
+                                                                        uint8_t *__restrict__ inside)
+{
+    __shared__ double s_box[32][16];
+    const long long i = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;
+    double px = 0, py = 0, pz = 0;
+    if (i < k) { px = (double)pts[i * stride]; py = (double)pts[i * stride + 1]; pz = (double)pts[i * stride + 2]; }
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int nb = min(32, B - b0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nb * 16; j += LPF_BLOCK) s_box[j >> 4][j & 15] = boxp[(size_t)b0 * 16 + j];
+        __syncthreads();
+        if (i < k)
+            for (int b = 0; b < nb; ++b)
+                inside[(size_t)(b0 + b) * k + i] =
+                    (uint8_t)(oriented ? lpf_oriented_inside(px, py, pz, s_box[b]) : lpf_aabb_inside(px, py, pz, s_box[b]));
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K8: masks -> label image.
 //   MODE 0: uint8, nonzero.  MODE 1: float, astype(uint8) != 0.  MODE 2: float, (x*255) -> u8 == 255.
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,565 @@
+"""The reference's function surface for the hot path, served by the HIP library.
+
+Names, argument meaning, return types and print formats follow
+``Coding_testes/V3_point_cloud_with_erosion.py`` / ``cvs_erosion.py`` /
+``V4_BBox_IoU_filtering.py`` (paths relative to /root/reference; line numbers cited per
+function).  Everything that touches per-point data goes through ``liblpf.so``
+(``_native.LpfContext``); what stays on the host is box-level scalar logic (8 corners per
+box), dict assembly, printing and CSV -- none of it is a fallback for the kernels, and
+there is no CPU path for them: without the GPU library these functions raise.
+
+YOLO segmentation and Open3D stay outside (reference: unchanged subsystems); the entry
+points take them as callables.
+"""
+import os
+from datetime import datetime
+
+import numpy as np
+
+from . import kitti360
+from ._native import LpfContext, LPF_MAX_MASKS
+
+_CONTEXTS = {}
+
+
+def get_context(device=0):
+    """Process-wide LpfContext of one GPU (created on first use)."""
+    ctx = _CONTEXTS.get(device)
+    if ctx is None:
+        ctx = _CONTEXTS[device] = LpfContext(device)
+    return ctx
+
+
+def _f32_points(points, what="points"):
+    """float32 view of caller points; refuses values a float32 cannot hold (the kernels
+    take the velodyne float32 format, V3:28, and there is no float64 point path)."""
+    p = np.asarray(points)
+    if p.dtype == np.float32:
+        return np.ascontiguousarray(p)
+    q = np.ascontiguousarray(p, dtype=np.float32)
+    if not np.array_equal(q.astype(np.float64), np.asarray(p, dtype=np.float64), equal_nan=True):
+        raise TypeError("%s must hold float32-representable values (velodyne .bin format)" % what)
+    return q
+
+
+def _mask_stack(masks, camera):
+    """[M,H,W] float32/uint8 array from the reference's mask list; identity resize only."""
+    m = np.asarray(masks)
+    if m.size == 0:
+        return np.zeros((0, camera.height, camera.width), np.uint8)
+    if m.ndim != 3 or m.shape[1:] != (camera.height, camera.width):
+        raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64); cv2.resize to another "
+                                  "size is not part of this path" % (camera.height, camera.width))
+    if m.dtype.kind == "f":
+        return np.ascontiguousarray(m, dtype=np.float32)
+    return np.ascontiguousarray(m.astype(np.uint8))
+
+
+# ---------------------------------------------------------------------------------------
+# box preparation (host scalars: 8 corners per box)
+# ---------------------------------------------------------------------------------------
+def filter_visible_bboxes(bboxes_3d, camera):
+    """Keep boxes with >= 2 corners in front (depth > 0.1) and inside the image (V3:121-140).
+    As in the reference the corners are projected without R_rect."""
+    filtered = []
+    for bbox in bboxes_3d:
+        if "corners_cam0" not in bbox:
+            continue
+        corners = np.array(bbox["corners_cam0"])
+        u, v, depth = camera.cam2image(corners.T)
+        ok = (depth > 0.1) & (u >= 0) & (u < camera.width) & (v >= 0) & (v < camera.height)
+        if np.sum(ok) >= 2:
+            filtered.append(bbox)
+    return filtered
+
+
+def transform_bboxes_to_velodyne(bboxes_3d, TrVeloToCam):
+    """Adds 'corners_velo' (list) to every box dict, in place (V3:41-52)."""
+    cam_to_velo = np.linalg.inv(TrVeloToCam)
+    for bbox in bboxes_3d:
+        if "corners_cam0" in bbox:
+            c = np.array(bbox["corners_cam0"])
+            homo = np.hstack([c, np.ones((c.shape[0], 1))])
+            bbox["corners_velo"] = np.matmul(cam_to_velo, homo.T).T[:, :3].tolist()
+    return bboxes_3d
+
+
+def _corners_velo(bboxes_3d):
+    """f64 [B,8,3] of the boxes that carry 'corners_velo' + their positions in the list."""
+    pos = [i for i, b in enumerate(bboxes_3d) if "corners_velo" in b]
+    if not pos:
+        return np.zeros((0, 8, 3)), pos
+    return np.array([bboxes_3d[i]["corners_velo"] for i in pos], np.float64).reshape(-1, 8, 3), pos
+
+
+# ---------------------------------------------------------------------------------------
+# projection + clip (reference: inline statements V3:565-569 and V3:584-592)
+# ---------------------------------------------------------------------------------------
+def project_points(points, TrVeloToRect, camera, depth_max=50.0, want_depth=True, device=0):
+    """(u, v, depth, valid_indices) of f32[N,4] velodyne points: u, v int64 as in the reference
+    (``np.round(...).astype(int)``), depth float64 (None unless want_depth), valid_indices =
+    ``np.where(valid)[0]``."""
+    ctx = get_context(device)
+    ctx.set_camera(TrVeloToRect, camera.K, camera.width, camera.height, 0.0, float(depth_max))
+    ctx.clear_masks()
+    ctx.clear_boxes()
+    r = ctx.run(_f32_points(points).reshape(-1, 4), want_float=want_depth, want_label=False)
+    return r["u"].astype(np.int64), r["v"].astype(np.int64), (r["depth"] if want_depth else None), r["valid_idx"]
+
+
+# ---------------------------------------------------------------------------------------
+# mask lookup (V3:211-233, cvs_erosion.py:148-162)
+# ---------------------------------------------------------------------------------------
+def extract_car_points_by_mask(points_valid, u_valid, v_valid, masks, camera, device=0):
+    """One point array per mask: ``points_valid[mask[v_valid, u_valid] > 0.5]``, empty masks give
+    a (0,3) float64 array.  The pixels are looked up by the same kernel the fused path uses
+    (run on the already-projected pixels with an identity camera)."""
+    pv = np.asarray(points_valid)
+    n = pv.shape[0]
+    stack = _mask_stack(masks, camera)
+    M = stack.shape[0]
+    sets = []
+    if M == 0:
+        return sets
+    ctx = get_context(device)
+    pix = np.zeros((n, 4), np.float32)
+    pix[:, 0] = np.asarray(u_valid)
+    pix[:, 1] = np.asarray(v_valid)
+    pix[:, 2] = 1.0
+    ctx.set_camera(np.eye(4), np.eye(3), camera.width, camera.height, 0.0, 2.0)
+    ctx.clear_boxes()
+    for m0 in range(0, M, LPF_MAX_MASKS):
+        ctx.set_masks(stack[m0:m0 + LPF_MAX_MASKS])
+        r = ctx.run(pix, want_uv=False, want_label=False)
+        for lst in r["inst_lists"]:
+            sets.append(pv[lst] if len(lst) else np.array([]).reshape(0, 3))
+    return sets
+
+
+# ---------------------------------------------------------------------------------------
+# box membership (V3:143-208)
+# ---------------------------------------------------------------------------------------
+def oriented_point_in_bbox(points, bbox_corners, device=0):
+    """bool[k]: inside the three slabs c1-c0, c3-c0, c4-c0 (closed), as V3:167-204."""
+    if len(points) == 0:
+        return np.array([])
+    p = _f32_points(points)
+    return get_context(device).points_in_boxes(p, np.asarray(bbox_corners, np.float64)[None], oriented=True)[0]
+
+
+def point_in_bbox(points, bbox_corners, device=0):
+    """bool[k]: inside the axis-aligned hull of the 8 corners (closed), as V3:143-164."""
+    if len(points) == 0:
+        return np.array([])
+    p = _f32_points(points)
+    return get_context(device).points_in_boxes(p, np.asarray(bbox_corners, np.float64)[None], oriented=False)[0]
+
+
+def _count_matrix(car_point_sets, corners, use_oriented, device=0, want_masks=False):
+    """counts[car, box] (+ the per-point inside matrix and set offsets) with ONE kernel call."""
+    sizes = [len(s) for s in car_point_sets]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    B = corners.shape[0]
+    counts = np.zeros((len(sizes), B), np.int64)
+    inside = None
+    if off[-1] and B:
+        cat = np.concatenate([_f32_points(s).reshape(-1, 3) for s in car_point_sets if len(s)], axis=0)
+        inside = get_context(device).points_in_boxes(cat, corners, oriented=use_oriented)
+        csum = np.concatenate([np.zeros((B, 1), np.int64), np.cumsum(inside, axis=1, dtype=np.int64)], axis=1)
+        counts = (csum[:, off[1:]] - csum[:, off[:-1]]).T.copy()
+    return counts, (inside if want_masks else None), off
+
+
+def _best_box(counts_row):
+    """First strict maximum starting from 0 (V3:353-376): (-1, 0) when no box holds a point."""
+    best, idx = 0, -1
+    for b, c in enumerate(counts_row):
+        if c > best:
+            best, idx = int(c), b
+    return idx, best
+
+
+def match_car_points_to_bboxes(car_point_sets, bboxes_3d, colors, min_points=10, use_oriented=True, device=0):
+    """[(corners_velo, rgb_color, count)] for the matched cars (V3:236-290)."""
+    matched = []
+    if not bboxes_3d or len(car_point_sets) == 0:
+        return matched
+    corners, pos = _corners_velo(bboxes_3d)
+    counts, _, _ = _count_matrix(car_point_sets, corners, use_oriented, device)
+    for car_idx, car_points in enumerate(car_point_sets):
+        if len(car_points) == 0:
+            continue
+        best, best_idx = 0, -1
+        for j, c in enumerate(counts[car_idx]):
+            if c > best and c >= min_points:
+                best, best_idx = int(c), pos[j]
+        if best_idx >= 0:
+            col = colors[car_idx]
+            matched.append((np.array(bboxes_3d[best_idx]["corners_velo"]), np.array([col[2], col[1], col[0]]) / 255.0, best))
+            print(f"  Matched car {car_idx} to bbox {best_idx} with {best} points")
+    return matched
+
+
+def stats_from_counts(car_sizes, counts, colors, min_points=10, box_positions=None):
+    """The reference's per-car dicts (cvs_erosion.py:165-229 key set) from integer counts:
+    car_sizes[m] = len(car_point_sets[m]), counts[m, b] = points of car m inside box b."""
+    out = []
+    for car_idx, total in enumerate(car_sizes):
+        total = int(total)
+        if total == 0:
+            continue
+        j, best = _best_box(counts[car_idx]) if counts.shape[1] else (-1, 0)
+        if j >= 0 and best >= min_points:
+            inside, outside = best, total - best
+            out.append({"car_id": car_idx, "matched_bbox_id": box_positions[j] if box_positions is not None else j,
+                        "total_points": total, "points_inside_bbox": inside, "points_outside_bbox": outside,
+                        "inside_percentage": (inside / total) * 100, "outside_percentage": (outside / total) * 100,
+                        "color": colors[car_idx], "_best_col": j, "_best_count": best})
+        else:
+            out.append({"car_id": car_idx, "matched_bbox_id": -1, "total_points": total, "points_inside_bbox": 0,
+                        "points_outside_bbox": total, "inside_percentage": 0.0, "outside_percentage": 100.0,
+                        "color": colors[car_idx], "_best_col": -1, "_best_count": best})
+    return out
+
+
+def calculate_car_point_statistics(car_point_sets, bboxes_3d, colors, min_points=10, use_oriented=True,
+                                   style="v3", device=0):
+    """Per-car inside/outside statistics (V3:320-428; ``style='cvs'`` gives cvs_erosion.py:165-229's
+    quieter variant without the array-valued keys).  Cars with no points get no row."""
+    stats = []
+    if not bboxes_3d or len(car_point_sets) == 0:
+        return stats
+    v3 = style == "v3"
+    if v3:
+        print(f"\n=== Car Point Statistics ===")
+    print(f"Total car detections: {len(car_point_sets)}")
+    print(f"Total 3D bounding boxes: {len(bboxes_3d)}")
+    corners, pos = _corners_velo(bboxes_3d)
+    counts, inside, off = _count_matrix(car_point_sets, corners, use_oriented, device, want_masks=v3)
+    rows = stats_from_counts([len(s) for s in car_point_sets], counts, colors, min_points, pos)
+    by_car = {r["car_id"]: r for r in rows}
+    for car_idx, car_points in enumerate(car_point_sets):
+        total = len(car_points)
+        if total == 0:
+            if v3:
+                print(f"\nCar {car_idx}: No points detected")
+            continue
+        r = by_car[car_idx]
+        j, best = r.pop("_best_col"), r.pop("_best_count")
+        if v3:
+            print(f"\nCar {car_idx}: {total} total points")
+            if r["matched_bbox_id"] >= 0:
+                r["corners_velo"] = np.array(bboxes_3d[r["matched_bbox_id"]]["corners_velo"])
+                r["inside_mask"] = inside[j, off[car_idx]:off[car_idx + 1]]
+                print(f"  ✓ Matched to 3D bbox {r['matched_bbox_id']}")
+                print(f"  │ Points inside bbox:  {r['points_inside_bbox']:4d} ({r['inside_percentage']:5.1f}%)")
+                print(f"  │ Points outside bbox: {r['points_outside_bbox']:4d} ({r['outside_percentage']:5.1f}%)")
+                print(f"  └ Total points:        {total:4d} (100.0%)")
+            else:
+                r["corners_velo"] = None
+                r["inside_mask"] = None
+                print(f"  ✗ No matching 3D bbox found (best match: {best} points < {min_points} threshold)")
+            r["car_points"] = car_points
+        stats.append(r)
+    return stats
+
+
+# ---------------------------------------------------------------------------------------
+# 2D IoU matching of V4 (V4:118-183) -- D x B scalars on the host
+# ---------------------------------------------------------------------------------------
+def calculate_iou_2d(box1, box2):
+    x1a, y1a, x1b, y1b = box1
+    x2a, y2a, x2b, y2b = box2
+    xa, ya = max(x1a, x2a), max(y1a, y2a)
+    xb, yb = min(x1b, x2b), min(y1b, y2b)
+    if xb <= xa or yb <= ya:
+        return 0.0
+    inter = (xb - xa) * (yb - ya)
+    union = (x1b - x1a) * (y1b - y1a) + (x2b - x2a) * (y2b - y2a) - inter
+    return inter / union if union > 0 else 0.0
+
+
+def match_detections_to_bboxes(boxes_2d, bboxes_3d, colors, camera, min_iou=0.25):
+    """[(corners_velo, rgb_color)] per detection whose best projected box beats min_iou (V4:140-183)."""
+    pairs = []
+    if not bboxes_3d or len(boxes_2d) == 0:
+        return pairs
+    proj = []
+    for bbox in bboxes_3d:
+        if "corners_cam0" not in bbox:
+            proj.append(None)
+            continue
+        u, v, depth = camera.cam2image(np.array(bbox["corners_cam0"]).T)
+        front = depth > 0
+        proj.append([np.min(u[front]), np.min(v[front]), np.max(u[front]), np.max(v[front])] if front.sum() else None)
+    for det_idx, box in enumerate(boxes_2d):
+        x1, y1, x2, y2 = box
+        best, best_idx = 0, -1
+        for j, pb in enumerate(proj):
+            if pb is None:
+                continue
+            iou = calculate_iou_2d([x1, y1, x2, y2], pb)
+            if iou > best and iou > min_iou:
+                best, best_idx = iou, j
+        if best_idx >= 0 and "corners_velo" in bboxes_3d[best_idx]:
+            c = colors[det_idx]
+            pairs.append((np.array(bboxes_3d[best_idx]["corners_velo"]), np.array([c[2], c[1], c[0]]) / 255.0))
+    return pairs
+
+
+# ---------------------------------------------------------------------------------------
+# reporting (V3:431-468, cvs_erosion.py:232-295)
+# ---------------------------------------------------------------------------------------
+def print_summary_statistics(car_statistics):
+    if not car_statistics:
+        print("\nNo car statistics to display.")
+        return
+    print(f"\n{'=' * 60}")
+    print(f"{'SUMMARY STATISTICS':^60}")
+    print(f"{'=' * 60}")
+    matched = [s for s in car_statistics if s["matched_bbox_id"] >= 0]
+    print(f"Total cars detected: {len(car_statistics)}")
+    print(f"Successfully matched: {len(matched)}")
+    print(f"Unmatched: {len(car_statistics) - len(matched)}")
+    if matched:
+        print(f"\n{'Car ID':<8} {'BBox ID':<8} {'Total':<8} {'Inside':<8} {'Outside':<8} {'Inside %':<10}")
+        print("-" * 60)
+        for s in matched:
+            print(f"{s['car_id']:<8} {s['matched_bbox_id']:<8} {s['total_points']:<8} {s['points_inside_bbox']:<8} "
+                  f"{s['points_outside_bbox']:<8} {s['inside_percentage']:<10.1f}")
+        tp = sum(s["total_points"] for s in matched)
+        ti = sum(s["points_inside_bbox"] for s in matched)
+        to = sum(s["points_outside_bbox"] for s in matched)
+        avg = (ti / tp * 100) if tp > 0 else 0
+        print("-" * 60)
+        print(f"{'TOTAL':<8} {'':<8} {tp:<8} {ti:<8} {to:<8} {avg:<10.1f}")
+
+
+CSV_COLUMNS = ("frame", "car_id", "matched_bbox_id", "total_points", "points_inside_bbox", "points_outside_bbox",
+               "inside_percentage", "outside_percentage", "is_matched", "timestamp")
+
+
+def csv_rows(car_statistics, frame_number, timestamp=None):
+    """The rows append_to_master_csv writes (cvs_erosion.py:243-255)."""
+    ts = timestamp if timestamp is not None else datetime.now().isoformat()
+    return [{"frame": frame_number, "car_id": s["car_id"], "matched_bbox_id": s["matched_bbox_id"],
+             "total_points": s["total_points"], "points_inside_bbox": s["points_inside_bbox"],
+             "points_outside_bbox": s["points_outside_bbox"], "inside_percentage": round(s["inside_percentage"], 2),
+             "outside_percentage": round(s["outside_percentage"], 2), "is_matched": s["matched_bbox_id"] >= 0,
+             "timestamp": ts} for s in car_statistics]
+
+
+def append_to_master_csv(car_statistics, frame_number, master_csv_path="results/master_car_statistics.csv", timestamp=None):
+    if not car_statistics:
+        return
+    import pandas as pd
+    d = os.path.dirname(master_csv_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    df = pd.DataFrame(csv_rows(car_statistics, frame_number, timestamp), columns=list(CSV_COLUMNS))
+    if os.path.exists(master_csv_path):
+        df.to_csv(master_csv_path, mode="a", header=False, index=False)
+        print(f"Appended {len(df)} rows to master CSV: {master_csv_path}")
+    else:
+        df.to_csv(master_csv_path, index=False)
+        print(f"Created new master CSV: {master_csv_path}")
+
+
+def analyze_master_csv(master_csv_path="results/master_car_statistics.csv"):
+    if not os.path.exists(master_csv_path):
+        print(f"Master CSV file not found: {master_csv_path}")
+        return
+    import pandas as pd
+    df = pd.read_csv(master_csv_path)
+    print(f"\n{'=' * 60}")
+    print(f"{'OVERALL ANALYSIS':^60}")
+    print(f"{'=' * 60}")
+    print(f"Total frames processed: {df['frame'].nunique()}")
+    print(f"Total car detections: {len(df)}")
+    print(f"Successfully matched cars: {df['is_matched'].sum()}")
+    print(f"Unmatched cars: {(~df['is_matched']).sum()}")
+    print(f"Average matching rate: {df['is_matched'].mean() * 100:.1f}%")
+    m = df[df["is_matched"] == True]  # noqa: E712  (same comparison as the reference)
+    if len(m) > 0:
+        print(f"\nMatched Cars Statistics:")
+        print(f"Average points per car: {m['total_points'].mean():.1f}")
+        print(f"Average inside percentage: {m['inside_percentage'].mean():.1f}%")
+        print(f"Min inside percentage: {m['inside_percentage'].min():.1f}%")
+        print(f"Max inside percentage: {m['inside_percentage'].max():.1f}%")
+    return df
+
+
+# ---------------------------------------------------------------------------------------
+# the fused per-frame path: one batched launch set for many frames
+# ---------------------------------------------------------------------------------------
+def default_colors(n):
+    """(int(i*60)%255, int(i*120)%255, int(i*180)%255), V3:100."""
+    return [(int(i * 60) % 255, int(i * 120) % 255, int(i * 180) % 255) for i in range(n)]
+
+
+class FrameInputs:
+    """What one frame hands to the hot path: velodyne points, detection masks and the
+    visible boxes already in velodyne coordinates."""
+
+    def __init__(self, frame, points, masks=None, bboxes_3d=None, colors=None, boxes_2d=None):
+        self.frame = frame
+        self.points = _f32_points(points).reshape(-1, 4)
+        self.masks = masks
+        self.bboxes_3d = bboxes_3d if bboxes_3d is not None else []
+        n = 0 if masks is None else len(masks)
+        self.colors = colors if colors is not None else default_colors(n)
+        self.boxes_2d = boxes_2d
+
+
+def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
+               erode_iters=0, v3_pipeline=False, device=0, ctx=None):
+    """Projection + clip + mask lookup + box counting + best-box scan for a list of
+    FrameInputs in ONE batched call (frames are independent units).  Returns one dict per
+    frame: valid_indices, u_valid, v_valid, points_valid, car_point_sets, bg_assigned,
+    count_mb, car_statistics (cvs_erosion key set) -- the integers are the kernels' output,
+    the dicts are assembled here."""
+    if not frames:
+        return []
+    ctx = ctx or get_context(device)
+    H, W = camera.height, camera.width
+    stacks = [_mask_stack(f.masks if f.masks is not None else [], camera) for f in frames]
+    M = max(s.shape[0] for s in stacks)
+    if M > LPF_MAX_MASKS:
+        raise NotImplementedError("more than %d detections in one frame" % LPF_MAX_MASKS)
+    is_f = any(s.dtype == np.float32 for s in stacks if s.shape[0])
+    batch = np.zeros((len(frames), M, H, W), np.float32 if is_f else np.uint8)
+    for i, s in enumerate(stacks):
+        if s.shape[0]:
+            batch[i, :s.shape[0]] = s
+    corners, positions = [], []
+    for f in frames:
+        c, pos = _corners_velo(f.bboxes_3d)
+        corners.append(c)
+        positions.append(pos)
+    ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
+    ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline)
+    ctx.set_boxes(corners, oriented=use_oriented)
+    res = ctx.run_batch([f.points for f in frames])
+    out = []
+    for f, r, s, pos in zip(frames, res, stacks, positions):
+        m = s.shape[0]
+        vi = r["valid_idx"]
+        pts_valid = f.points[vi, :3]
+        sets = [f.points[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in r["inst_lists"][:m]]
+        stats = []
+        if f.bboxes_3d and m:
+            stats = stats_from_counts(r["inst_count"][:m], r["count_mb"][:m], f.colors, min_points, pos)
+            for d in stats:
+                d.pop("_best_col"), d.pop("_best_count")
+        out.append(dict(frame=f.frame, valid_indices=vi, u_valid=r["u"][vi].astype(np.int64), v_valid=r["v"][vi].astype(np.int64),
+                        points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_bits"][vi] != 0,
+                        count_mb=r["count_mb"][:m], car_statistics=stats, n_valid=r["n_valid"]))
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# entry points (frame loops of cvs_erosion.py:298-379 and V3:516-641)
+# ---------------------------------------------------------------------------------------
+def sequence_setup(kitti360_path, seq=0, cam_id=0):
+    """camera, TrVeloToCam, TrVeloToRect and the velodyne reader, composed as V3:520-535."""
+    sequence = "2013_05_28_drive_%04d_sync" % seq
+    camera = kitti360.CameraPerspective(kitti360_path, sequence, cam_id)
+    velo_to_cam, velo_to_rect = kitti360.velo_to_rect_transforms(kitti360_path, camera, cam_id)
+    velo = kitti360.Kitti360Viewer3DRaw(seq=seq, root_dir=kitti360_path)
+    return sequence, camera, velo_to_cam, velo_to_rect, velo
+
+
+def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None):
+    """The reference's per-frame loading + skip rules (cvs_erosion.py:320-369): a frame is
+    dropped when its scan, its box file, its image or its detections are missing."""
+    sequence = "2013_05_28_drive_%04d_sync" % seq
+    bbox_dir = os.path.join(kitti360_path, "bboxes_3D_cam0")
+    todo = velo.available_frames() if frames is None else list(frames)
+    print(f"Found {len(todo)} frames to process")
+    items = []
+    for frame in todo:
+        print(f"\nProcessing frame {frame}...")
+        try:
+            points = velo.loadVelodyneData(frame)
+        except Exception as e:  # same breadth as the reference
+            print(f"Failed to load frame {frame}: {e}")
+            continue
+        raw = kitti360.load_bounding_boxes(os.path.join(bbox_dir, f"BBoxes_{frame}.json"))
+        if not raw:
+            continue
+        boxes = transform_bboxes_to_velodyne(filter_visible_bboxes(raw, camera), velo_to_cam)
+        image_path = os.path.join(kitti360_path, "data_2d_raw", sequence, f"image_{cam_id:02d}",
+                                  "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
+        if not os.path.isfile(image_path):
+            continue
+        seg = segmenter(image_loader(image_path) if image_loader else image_path)
+        _, masks, colors, boxes_2d, _ = seg
+        if masks is None or len(masks) == 0:
+            continue
+        items.append(FrameInputs(frame, points, masks, boxes, colors, boxes_2d))
+    return items
+
+
+def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None,
+                   master_csv_path="results/master_car_statistics.csv", frames=None, batch_frames=32,
+                   erode_iters=0, v3_pipeline=False, device=0, timestamp=None):
+    """cvs_erosion.process_frames (cvs_erosion.py:298-379): writes the master CSV and prints the
+    overall analysis.  ``segmenter(image) -> (img, masks, colors, boxes, confidences)`` is the
+    YOLO stage (unchanged subsystem); pass masks it already eroded, or raw masks plus
+    ``erode_iters=1, v3_pipeline=True`` to erode on the GPU."""
+    if segmenter is None:
+        raise ValueError("process_frames needs the segmentation callable (YOLO stays outside this package)")
+    root = kitti360_path or os.environ["KITTI360_DATASET"]
+    _, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames)
+    for i in range(0, len(items), batch_frames):
+        for r in run_frames(items[i:i + batch_frames], velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
+            if r["n_valid"] == 0:
+                continue
+            if r["car_statistics"]:
+                append_to_master_csv(r["car_statistics"], r["frame"], master_csv_path, timestamp)
+    return analyze_master_csv(master_csv_path)
+
+
+def process_frame_with_statistics(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None,
+                                  visualizer=None, frames=None, erode_iters=0, v3_pipeline=False, device=0):
+    """V3's entry point (V3:516-641) without the blocking Open3D window: per frame it prints the
+    statistics table and hands (frame, car_statistics, points_valid, bg_assigned) to
+    ``visualizer`` when one is given.  bg_assigned is V4's vectorised form of V3:609-616."""
+    if segmenter is None:
+        raise ValueError("process_frame_with_statistics needs the segmentation callable")
+    root = kitti360_path or os.environ["KITTI360_DATASET"]
+    _, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames)
+    results = []
+    for r, item in zip(run_frames(items, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device), items):
+        if r["n_valid"] == 0:
+            continue
+        print_summary_statistics(r["car_statistics"])
+        if visualizer is not None:
+            visualizer(r["frame"], r["car_statistics"], r["points_valid"], r["bg_assigned"])
+        results.append(r)
+    return results
+
+
+def process_frame(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None, visualizer=None,
+                  frames=None, device=0):
+    """V4's entry point (V4:213-336): depth < 30 clip, per-mask point sets, ``bg_assigned`` and the
+    2D-IoU box matching; the Open3D window is replaced by the optional ``visualizer`` callable,
+    which receives (frame, car_point_sets, colors, remaining_points, matched_pairs)."""
+    if segmenter is None:
+        raise ValueError("process_frame needs the segmentation callable")
+    root = kitti360_path or os.environ["KITTI360_DATASET"]
+    _, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames)
+    results = []
+    for r, item in zip(run_frames(items, velo_to_rect, camera, 30.0, 10, True, 0, False, device), items):
+        if r["n_valid"] == 0:
+            continue
+        r["remaining_points"] = r["points_valid"][~r["bg_assigned"]]
+        r["matched_pairs"] = match_detections_to_bboxes(item.boxes_2d, item.bboxes_3d, item.colors, camera)
+        print(f"Visualizing frame {r['frame']} with {sum(len(s) > 0 for s in r['car_point_sets']) + 1 + len(r['matched_pairs'])} objects")
+        if visualizer is not None:
+            visualizer(r["frame"], r["car_point_sets"], item.colors, r["remaining_points"], r["matched_pairs"])
+        results.append(r)
+    return results

@@ -1,0 +1,124 @@
+"""Host-side pieces of lidar_object_detection_amd.pipeline / kitti360 (no GPU): box
+preparation, 2D IoU matching, best-box scan, CSV rows -- against the golden vectors the
+reference's own functions produced."""
+import io
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_frames, load_golden
+from lidar_object_detection_amd import kitti360, pipeline
+
+FRAMES = [r for r in golden_frames()["frames"] if "skipped" not in r]
+
+
+def _camera(calib):
+    return kitti360.CameraPerspective.from_arrays(calib["K"], calib["R_rect"], int(calib["width"]), int(calib["height"]))
+
+
+def _raw_boxes(g):
+    return [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+def test_box_preparation_matches_reference(rec, calib):
+    g = load_golden(rec["frame"])
+    cam = _camera(calib)
+    raw = _raw_boxes(g)
+    vis = pipeline.filter_visible_bboxes(raw, cam)
+    assert [raw.index(b) for b in vis] == g["visible_pos"].tolist()
+    out = pipeline.transform_bboxes_to_velodyne(vis, calib["TrVeloToCam"])
+    assert out is vis and all("corners_velo" in b for b in vis)          # in place, as the reference
+    got = np.array([b["corners_velo"] for b in vis]).reshape(-1, 8, 3)
+    assert np.array_equal(got, g["corners_velo"])
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+@pytest.mark.parametrize("kind", ["rect5", "edge"])
+def test_iou_matching_matches_reference(rec, kind, calib):
+    g = load_golden(rec["frame"])
+    cam = _camera(calib)
+    vis = pipeline.transform_bboxes_to_velodyne(pipeline.filter_visible_bboxes(_raw_boxes(g), cam), calib["TrVeloToCam"])
+    boxes2d = g["boxes2d_" + kind]
+    pairs = pipeline.match_detections_to_bboxes(boxes2d, vis, pipeline.default_colors(len(boxes2d)), cam)
+    assert np.array_equal(np.array([p[0] for p in pairs]).reshape(-1, 8, 3), g["iou_match_corners_" + kind])
+    assert np.array_equal(np.array([p[1] for p in pairs]).reshape(-1, 3), g["iou_match_color_" + kind])
+
+
+def test_iou2d_known_answers():
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "iou2d_kat.npz"))
+    got = np.array([pipeline.calculate_iou_2d(list(a), list(b)) for a, b in zip(k["box1"], k["box2"])])
+    assert np.array_equal(got, k["iou"])
+    assert got[:8].tolist() == [1.0] * 8 and not got[8:16].any()
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+@pytest.mark.parametrize("tag", ["rect5_d50", "rect5_d30", "edge_d50"])
+def test_stats_from_counts_matches_reference(rec, tag):
+    """The dict assembly + best-box scan, fed with the reference's own count matrix."""
+    g = load_golden(rec["frame"])
+    counts, sizes = g["count_mb_" + tag], g["inst_count_" + tag]
+    if counts.shape[1] == 0:
+        pytest.skip("no visible boxes: the reference returns no rows")
+    rows = pipeline.stats_from_counts(sizes, counts, pipeline.default_colors(len(sizes)), 10)
+    for key in ("car_id", "matched_bbox_id", "total_points", "points_inside_bbox", "points_outside_bbox"):
+        assert [r[key] for r in rows] == g["stats_%s_%s" % (key, tag)].tolist(), key
+    assert np.array_equal(np.array([r["inside_percentage"] for r in rows]), g["stats_inside_percentage_" + tag])
+    assert np.array_equal(np.array([r["outside_percentage"] for r in rows]), g["stats_outside_percentage_" + tag])
+
+
+def test_best_box_is_first_strict_maximum():
+    assert pipeline._best_box(np.array([0, 0, 0])) == (-1, 0)
+    assert pipeline._best_box(np.array([3, 7, 7, 2])) == (1, 7)
+    assert pipeline._best_box(np.array([], np.int64)) == (-1, 0)
+
+
+def test_master_csv_roundtrip(tmp_path):
+    stats = [{"car_id": 0, "matched_bbox_id": 4, "total_points": 2926, "points_inside_bbox": 2526,
+              "points_outside_bbox": 400, "inside_percentage": 2526 / 2926 * 100, "outside_percentage": 400 / 2926 * 100, "color": (0, 0, 0)},
+             {"car_id": 2, "matched_bbox_id": -1, "total_points": 7, "points_inside_bbox": 0, "points_outside_bbox": 7,
+              "inside_percentage": 0.0, "outside_percentage": 100.0, "color": (1, 2, 3)}]
+    path = str(tmp_path / "results" / "master_car_statistics.csv")
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        pipeline.append_to_master_csv(stats, 100, path, timestamp="T0")
+        pipeline.append_to_master_csv(stats[:1], 250, path, timestamp="T1")
+        pipeline.append_to_master_csv([], 360, path)
+        df = pipeline.analyze_master_csv(path)
+    lines = open(path).read().splitlines()
+    assert lines[0] == ",".join(pipeline.CSV_COLUMNS)
+    assert lines[1] == "100,0,4,2926,2526,400,86.33,13.67,True,T0"
+    assert lines[2] == "100,2,-1,7,0,7,0.0,100.0,False,T0"
+    assert lines[3] == "250,0,4,2926,2526,400,86.33,13.67,True,T1" and len(lines) == 4
+    text = out.getvalue()
+    assert "Created new master CSV" in text and "Appended 1 rows" in text
+    assert "Total frames processed: 2" in text and "Successfully matched cars: 2" in text
+    assert "Average matching rate: 66.7%" in text and "Average inside percentage: 86.3%" in text
+    assert len(df) == 3
+
+
+def test_calibration_reader_known_answers(tmp_path):
+    """perspective.txt / calib_cam_to_pose.txt / calib_cam_to_velo.txt formats (hand-checked values)."""
+    cal = tmp_path / "calibration"
+    cal.mkdir()
+    (cal / "perspective.txt").write_text(
+        "S_rect_00: 1408.000000 376.000000\nR_rect_00: 0.999974 -0.007141 -0.000089 0.007141 0.999969 -0.003247 0.000112 0.003247 0.999995\n"
+        "P_rect_00: 552.554261 0.000000 682.049453 0.000000 0.000000 552.554261 238.769549 0.000000 0.000000 0.000000 1.000000 0.000000\n"
+        "S_rect_01: 1408.000000 376.000000\nR_rect_01: 1 0 0 0 1 0 0 0 1\n"
+        "P_rect_01: 552.554261 0.000000 682.049453 -328.318735 0.000000 552.554261 238.769549 0.000000 0.000000 0.000000 1.000000 0.000000\n")
+    (cal / "calib_cam_to_pose.txt").write_text("".join("image_%02d: 1 0 0 %d 0 1 0 0 0 0 1 0\n" % (i, i) for i in range(4)))
+    (cal / "calib_cam_to_velo.txt").write_text("0 -1 0 0.5 0 0 -1 0.25 1 0 0 -0.125\n")
+    cam = kitti360.CameraPerspective(str(tmp_path), "seq", 0)
+    assert (cam.width, cam.height) == (1408, 376)
+    assert cam.K.shape == (3, 4) and cam.K[0, 0] == 552.554261 and cam.K[1, 2] == 238.769549
+    assert cam.R_rect.shape == (4, 4) and cam.R_rect[0, 1] == -0.007141 and cam.R_rect[3, 3] == 1.0
+    cam1 = kitti360.CameraPerspective(str(tmp_path), "seq", 1)
+    assert cam1.K[0, 3] == -328.318735
+    T = kitti360.loadCalibrationRigid(str(cal / "calib_cam_to_velo.txt"))
+    assert T.shape == (4, 4) and T[0, 1] == -1 and T[2, 3] == -0.125 and T[3].tolist() == [0, 0, 0, 1]
+    u, v, d = cam.cam2image(np.array([[1.0, 0.0, -2.0], [0.5, 0.0, 1.0], [2.0, 0.0, 4.0]]))
+    assert d.tolist() == [2.0, -1e-6, 4.0]                            # zero depth is patched, sign kept
+    assert u[0] == int(np.round((552.554261 * 1.0 + 682.049453 * 2.0) / 2.0)) and v[2] == int(np.round((552.554261 + 238.769549 * 4.0) / 4.0))
+    with pytest.raises(RuntimeError):
+        kitti360.Kitti360Viewer3DRaw(seq=0, root_dir=str(tmp_path)).loadVelodyneData(5)
