@@ -37,6 +37,21 @@ ALGO_BYTES_PER_POINT = 28          # 16 B xyzI read + 8 B (u,v) write + 4 B labe
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_traffic(points_per_launch):
+    """HBM bytes per launch of the project+label kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as tools/pmc_summary.py documents), or
+    None when no committed pass matches this launch size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_f8x2M.json")
+    if points_per_launch != 8 * 2_000_000 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if "lpf_k1_project_t" in k:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(scene, T, K, W, H, budget_s):
     """Reference NumPy statements (oracle/numpy_path.py) on this host, bounded sample."""
     from oracle import numpy_path as npp
@@ -234,7 +249,7 @@ def main():
             dur_s = 1e-3 * k1_ms / k1_n
             achieved = ALGO_BYTES_PER_POINT * ntot / dur_s / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(ntot),
                                 "kernel": "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,
                                 "how": "second pass of the same %d steps with hipEvent pairs around the kernel on its stream "
