@@ -46,9 +46,14 @@ struct lpf_ctx {
     std::vector<int32_t> box_off;     // F+1
     DevBuf boxp;                      // [Btot][16] double
     DevBuf boxq;                      // [Btot][8] float conservative AABB
+    DevBuf cand;                      // candidate-box grid (see build_candidates)
+    std::vector<double> box_verts;    // [Btot][8][3] vertices of each box's accepted region (velodyne frame)
+    std::vector<char> box_bounded;    // [Btot] 0: region unbounded / degenerate -> candidate everywhere
+    std::vector<long long> cand_off;  // [F] first word of frame f's grid
+    bool cand_dirty = true;
 
     // per-run scratch
-    DevBuf frames, segs, vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, label_scratch;
+    DevBuf frames, segs, vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
@@ -116,7 +121,7 @@ int use_device(lpf_ctx *c)
 
 // box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) plus a
 // conservative float AABB of the accepted region, used only to skip hopeless (point, box) pairs.
-void box_params(const double *c, int oriented, double *o, float *q)
+void box_params(const double *c, int oriented, double *o, float *q, double *verts = nullptr, char *bounded_out = nullptr)
 {
     for (int i = 0; i < 16; ++i) o[i] = 0.0;
     double lo[3], hi[3];
@@ -153,6 +158,7 @@ void box_params(const double *c, int oriented, double *o, float *q)
                 const double r[3] = {(sg & 1) ? vv[0] : 0.0, (sg & 2) ? vv[1] : 0.0, (sg & 4) ? vv[2] : 0.0};
                 for (int k = 0; k < 3; ++k) {
                     const double x = c[k] + inv[k][0] * r[0] + inv[k][1] * r[1] + inv[k][2] * r[2];
+                    if (verts) verts[3 * sg + k] = x;
                     if (x < lo[k]) lo[k] = x;
                     if (x > hi[k]) hi[k] = x;
                 }
@@ -169,7 +175,12 @@ void box_params(const double *c, int oriented, double *o, float *q)
             o[k] = a; o[3 + k] = b; lo[k] = a; hi[k] = b;
             if (!(a == a) || !(b == b)) bounded = false;
         }
+        if (verts)
+            for (int sg = 0; sg < 8; ++sg)
+                for (int k = 0; k < 3; ++k) verts[3 * sg + k] = ((sg >> k) & 1) ? hi[k] : lo[k];
     }
+    for (int k = 0; k < 3; ++k) if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) bounded = false;
+    if (bounded_out) *bounded_out = bounded ? 1 : 0;
     for (int k = 0; k < 3; ++k) {
         if (!bounded || !std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
             q[k] = -INFINITY; q[4 + k] = INFINITY;
@@ -180,6 +191,66 @@ void box_params(const double *c, int oriented, double *o, float *q)
         }
     }
     q[3] = 0.f; q[7] = 0.f;
+}
+
+// Candidate grid: bit b of cell (cy, cx) of frame f is set when box b's accepted region can
+// project into that 32x32-pixel cell of the image.  The region is convex and the camera is a
+// pinhole, so for a region entirely in front of the camera the projections of its 8 vertices
+// bound its image; regions that reach behind the camera (or are unbounded) are candidates
+// everywhere.  Purely a work-skipping structure: every candidate still takes the exact test.
+#define LPF_CELL_SHIFT 5
+int build_candidates(lpf_ctx *c, int F)
+{
+    const int cs = LPF_CELL_SHIFT, cw = (c->W + (1 << cs) - 1) >> cs, ch = (c->H + (1 << cs) - 1) >> cs;
+    const size_t ncell = (size_t)cw * ch;
+    c->cand_off.assign((size_t)F, 0);
+    size_t total = 0;
+    for (int f = 0; f < F; ++f) {
+        const int B = c->box_off[f + 1] - c->box_off[f];
+        c->cand_off[f] = (long long)total;
+        total += ncell * (size_t)((B + 63) / 64);
+    }
+    std::vector<unsigned long long> g(total ? total : 1, 0ull);
+    for (int f = 0; f < F; ++f) {
+        const int B = c->box_off[f + 1] - c->box_off[f], words = (B + 63) / 64;
+        unsigned long long *gf = g.data() + c->cand_off[f];
+        for (int b = 0; b < B; ++b) {
+            const int gb = c->box_off[f] + b;
+            int x0 = 0, x1 = cw - 1, y0 = 0, y1 = ch - 1;
+            bool everywhere = !c->box_bounded[gb];
+            if (!everywhere) {
+                double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+                for (int k = 0; k < 8 && !everywhere; ++k) {
+                    const double *p = &c->box_verts[(size_t)gb * 24 + 3 * k];
+                    double cam[3];
+                    for (int i = 0; i < 3; ++i) cam[i] = c->T[4 * i] * p[0] + c->T[4 * i + 1] * p[1] + c->T[4 * i + 2] * p[2] + c->T[4 * i + 3];
+                    const double qx = c->K[0] * cam[0] + c->K[1] * cam[1] + c->K[2] * cam[2];
+                    const double qy = c->K[3] * cam[0] + c->K[4] * cam[1] + c->K[5] * cam[2];
+                    const double d = c->K[6] * cam[0] + c->K[7] * cam[1] + c->K[8] * cam[2];
+                    if (!(d > 1e-3) || !std::isfinite(qx) || !std::isfinite(qy)) { everywhere = true; break; }
+                    const double u = qx / d, v = qy / d;
+                    if (u < umin) umin = u; if (u > umax) umax = u;
+                    if (v < vmin) vmin = v; if (v > vmax) vmax = v;
+                }
+                if (!everywhere) {
+                    umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;        // rounding of (u, v) + slack
+                    if (umax < 0 || vmax < 0 || umin > c->W || vmin > c->H) continue;   // never seen by a valid point
+                    x0 = umin <= 0 ? 0 : (int)umin >> cs; y0 = vmin <= 0 ? 0 : (int)vmin >> cs;
+                    x1 = umax >= c->W ? cw - 1 : (int)umax >> cs; y1 = vmax >= c->H ? ch - 1 : (int)vmax >> cs;
+                    if (x1 > cw - 1) x1 = cw - 1;
+                    if (y1 > ch - 1) y1 = ch - 1;
+                }
+            }
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) gf[((size_t)y * cw + x) * words + (b >> 6)] |= 1ull << (b & 63);
+        }
+    }
+    int rc;
+    if ((rc = reserve(c, c->cand, g.size() * 8))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(c->cand.p, g.data(), g.size() * 8, hipMemcpyHostToDevice, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));          // g is a local
+    c->cand_dirty = false;
+    return LPF_OK;
 }
 
 template <typename T>
@@ -278,8 +349,8 @@ void lpf_destroy(lpf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->frames, &c->vbal, &c->mbal,
-                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->label_scratch, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->vbal, &c->mbal,
+                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->mlist, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -322,6 +393,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     memcpy(c->K, K, sizeof c->K);
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
     c->have_camera = true;
+    c->cand_dirty = true;                    // the candidate grid depends on T, K, W, H
     return LPF_OK;
 }
 
@@ -378,7 +450,12 @@ int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int
     if (Btot > 0 && !corners) return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL");
     std::vector<double> bp((size_t)Btot * 16);
     std::vector<float> bq((size_t)Btot * 8);
-    for (int b = 0; b < Btot; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data() + (size_t)b * 8);
+    c->box_verts.assign((size_t)Btot * 24, 0.0);
+    c->box_bounded.assign((size_t)Btot, 0);
+    for (int b = 0; b < Btot; ++b)
+        box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data() + (size_t)b * 8,
+                   c->box_verts.data() + (size_t)b * 24, c->box_bounded.data() + b);
+    c->cand_dirty = true;
     int rc;
     if ((rc = reserve(c, c->boxp, bp.size() * sizeof(double)))) return rc;
     if ((rc = reserve(c, c->boxq, bq.size() * sizeof(float)))) return rc;
@@ -415,6 +492,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 
     // ---- segmentation: fixed 2048-point segments (K2 blocks); K1 tiles subdivide them ------
     const int64_t seg_pts = LPF_SEG_QUANTUM;
+    if (c->box_F && c->cand_dirty && (rc = build_candidates(c, F))) return rc;
     c->h_frames.resize(F);
     int nseg_total = 0;
     for (int f = 0; f < F; ++f) {
@@ -428,6 +506,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.B = c->box_F ? c->box_off[f + 1] - c->box_off[f] : 0;
         fr.inst_base = (long long)f * out->inst_cap;
         fr.pad = f;
+        fr.cand_off = c->box_F ? c->cand_off[f] : 0;
+        fr.cand_words = (fr.B + 63) / 64;
+        fr.pad2 = 0;
     }
     const int nseg_cap = nseg_total > 0 ? nseg_total : 1;
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
@@ -451,6 +532,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
     P.label_img = (M > 0) ? c->label_cur : nullptr;
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
+    P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     P.vbal = (unsigned long long *)c->vbal.p; P.mbal = (unsigned long long *)c->mbal.p;
     P.seg_tab = (uint4 *)c->seg_tab.p; P.seg_pre = (uint4 *)c->seg_pre.p; P.frame_tot = (unsigned *)c->frame_tot.p;
     P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)c->cnt.p;
@@ -489,9 +571,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         P.summary = out->summary;
     }
 #undef LPF_OUTBUF
-    if (!P.label_bits) {                 // K2 re-reads the labels of masked points
-        if ((rc = reserve(c, c->label_scratch, n * 4))) return rc;
-        P.label_bits = (uint32_t *)c->label_scratch.p;
+    if (M > 0) {                         // K1 -> K2 hand-off of the masked points (sparse writes into N slots)
+        if ((rc = reserve(c, c->mlist, n * 16))) return rc;
+        P.mlist = (float4 *)c->mlist.p;
     }
 
     // The frame table only changes when the batch geometry does; upload it then (and wait, the
@@ -523,6 +605,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             LPF_HIP(c, hipEventRecord(e0, c->stream));
         }
         // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
+        P.tile_pts = (Ntot <= (4ll << 20)) ? 512 : 1024;
         if (Ntot <= (4ll << 20))
             hipLaunchKernelGGL((lpf_k1_project_t<2, LPF_K1_FLAGS>), dim3(nseg_total * (unsigned)(seg_pts / 512)), dim3(LPF_BLOCK), 0, c->stream, P);
         else
@@ -540,7 +623,16 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
     }
     if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
-        hipLaunchKernelGGL((lpf_k2_lists), dim3((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES), dim3(LPF_BLOCK), 0, c->stream, P);
+        const dim3 g2((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES);
+        static const int k2_ablate = getenv("LPF_DEV_K2_ABLATE") ? atoi(getenv("LPF_DEV_K2_ABLATE")) : 0;   // profiling aid only
+        if (k2_ablate == 4) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 8) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 2) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 16) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOEXACT>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 32) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 96) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND | LPF_F2_LAB_NOPROJ>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else if (k2_ablate == 12) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        else hipLaunchKernelGGL((lpf_k2_lists), g2, dim3(LPF_BLOCK), 0, c->stream, P);
         LPF_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);

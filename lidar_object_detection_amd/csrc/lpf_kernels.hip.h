@@ -19,7 +19,7 @@
 #include <stdint.h>
 
 #define LPF_BLOCK 256            // 4 waves of 64
-#define LPF_SEG_QUANTUM 2048     // points per segment (K2 block); every K1 tile size divides it
+#define LPF_SEG_QUANTUM 4096     // points per segment = 64 ballot rows = one K2 wave; every K1 tile size divides it
 #define LPF_TAB_ROWS 36          // counters per segment: 0 valid, 1 masked, 2+m instance m (34 used)
 #define LPF_TAB_GROUPS 9         // stored as uint4 groups: counter c lives in group c>>2, component c&3
 
@@ -32,6 +32,9 @@ struct LpfFrame {                // one per frame, device + host copy
     int box_off;                 // first box of the frame
     int B;                       // boxes of the frame
     int pad;                     // frame index (set by the host)
+    long long cand_off;          // first word of the frame's candidate-box grid
+    int cand_words;              // 64-bit words per grid cell = ceil(B / 64)
+    int pad2;
 };
 
 struct LpfParams {
@@ -52,6 +55,8 @@ struct LpfParams {
     const uint32_t *label_img;   // [F][H][W] or null
     const double *boxp;          // [Btot][16] exact box parameters
     const float *boxq;           // [Btot][8]  conservative float AABB {lo xyz, hi xyz}
+    const unsigned long long *cand;   // per frame [cells][cand_words]: boxes whose accepted region can project into the cell
+    int cell_w, cell_shift;      // cells per image row, log2(cell size in pixels)
     // outputs (nullable)
     int2 *uv;
     uint32_t *label_bits;
@@ -67,6 +72,9 @@ struct LpfParams {
     uint4 *seg_pre;              // [LPF_TAB_GROUPS][nseg_cap] written by the scan (see lpf_scan_segments)
     unsigned *frame_tot;         // [F][LPF_TAB_ROWS] totals per frame
     unsigned *cnt;               // [M*Btot] inside counts (self-cleaned by K3)
+    float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
+                                 // bits} of its masked points in point order (K2 never gathers from the cloud)
+    int tile_pts;                // points per K1 tile of this launch (4 waves)
 };
 
 __device__ __forceinline__ int lpf_lane() { return threadIdx.x & 63; }
@@ -124,6 +132,22 @@ __device__ __forceinline__ void lpf_div2(double qx, double qy, double ad, double
         uf = qx / ad;
         vf = qy / ad;
     }
+}
+
+// One point through K1 + K2 of the reference (V3:565-568): rows of T and K as k-ordered fma
+// chains (= OpenBLAS dgemm on these shapes), depth 0 -> -1e-6, x/|z| and y/|z|.
+__device__ __forceinline__ void lpf_project_point(const LpfParams &P, float fx, float fy, float fz,
+                                                  double &uf, double &vf, double &d)
+{
+    const double x = (double)fx, y = (double)fy, z = (double)fz;
+    double cx = P.T[0] * x; cx = fma(P.T[1], y, cx); cx = fma(P.T[2],  z, cx); cx = cx + P.T[3];
+    double cy = P.T[4] * x; cy = fma(P.T[5], y, cy); cy = fma(P.T[6],  z, cy); cy = cy + P.T[7];
+    double cz = P.T[8] * x; cz = fma(P.T[9], y, cz); cz = fma(P.T[10], z, cz); cz = cz + P.T[11];
+    double qx = P.K[0] * cx; qx = fma(P.K[1], cy, qx); qx = fma(P.K[2], cz, qx);
+    double qy = P.K[3] * cx; qy = fma(P.K[4], cy, qy); qy = fma(P.K[5], cz, qy);
+    d = P.K[6] * cx; d = fma(P.K[7], cy, d); d = fma(P.K[8], cz, d);
+    if (d == 0.0) d = -1e-6;
+    lpf_div2(qx, qy, fabs(d), uf, vf);
 }
 
 // ------------------------------------------------------------------------------------
@@ -199,17 +223,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
                 uf = (double)p[r].x; vf = (double)p[r].y; d = (double)p[r].z;
                 ru = uf + 700.0; rv = vf + 100.0;
             } else {
-                const double x = (double)p[r].x, y = (double)p[r].y, z = (double)p[r].z;
-                // K1: rows of T as k-ordered fma chains (= OpenBLAS dgemm on this shape)
-                double cx = P.T[0] * x; cx = fma(P.T[1], y, cx); cx = fma(P.T[2],  z, cx); cx = cx + P.T[3];
-                double cy = P.T[4] * x; cy = fma(P.T[5], y, cy); cy = fma(P.T[6],  z, cy); cy = cy + P.T[7];
-                double cz = P.T[8] * x; cz = fma(P.T[9], y, cz); cz = fma(P.T[10], z, cz); cz = cz + P.T[11];
-                // K2: cam2image
-                double qx = P.K[0] * cx; qx = fma(P.K[1], cy, qx); qx = fma(P.K[2], cz, qx);
-                double qy = P.K[3] * cx; qy = fma(P.K[4], cy, qy); qy = fma(P.K[5], cz, qy);
-                d = P.K[6] * cx; d = fma(P.K[7], cy, d); d = fma(P.K[8], cz, d);
-                if (d == 0.0) d = -1e-6;
-                lpf_div2(qx, qy, fabs(d), uf, vf);
+                lpf_project_point(P, p[r].x, p[r].y, p[r].z, uf, vf, d);
                 ru = rint(uf); rv = rint(vf);                   // np.round: half to even
             }
             // K3: clip
@@ -242,13 +256,18 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
         for (int r = 0; r < ROWS; ++r) {
             const int idx = wbase + r * 64;
             uint32_t l = lab[r];
-            if (idx < seg_end && !(FL & LPF_F_LAB_NOSTORE)) {
+            if (idx < seg_end && P.label_bits && !(FL & LPF_F_LAB_NOSTORE)) {
                 if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + fr.pt_off + idx);
                 else P.label_bits[fr.pt_off + idx] = l;
             }
             const unsigned long long vb = __ballot(valid[r]);
             const unsigned long long mb = __ballot(l != 0);
             if (lane == r) { myv = vb; mym = mb; }
+            // the wave's masked points {x, y, z, label}, compacted in point order at the wave's own
+            // first slots: K2 reads them back coalesced instead of gathering from the cloud
+            if (l && P.mlist && !(FL & LPF_F_LAB_NOSTORE))
+                P.mlist[fr.pt_off + (wbase - lane) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
+                    make_float4(p[r].x, p[r].y, p[r].z, __uint_as_float(l));
             nvalid_w += __popcll(vb);
             nmask_w += __popcll(mb);
             while (l) {                                     // rare: per-instance counts
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments_t(const LpfParams
 }
 
 // ------------------------------------------------------------------------------------
-// K2: one WAVE = one segment of LPF_SEG_QUANTUM (2048) points = 32 ballot rows; four
+// K2: one WAVE = one segment of LPF_SEG_QUANTUM (4096) points = 64 ballot rows, one per lane; four
 // independent waves per block, no block barriers.  Memory round trips on a wave's critical
 // path: {segment record, ballots, prefixes} -> {labels + xyz of the masked points, box
 // bounds} -> stores / atomics.
@@ -463,19 +482,15 @@ __device__ __forceinline__ unsigned long long lpf_rl64_var(unsigned long long v,
     return (unsigned long long)(unsigned)__shfl((int)(unsigned)v, l) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(v >> 32), l) << 32);
 }
 
-// Set bits of 32 ballots (lane r < 32 holds row r) -> ascending list in LDS.  Lane r walks the
-// low half of its row, lane r + 32 the high half: work is O(set bits), not O(rows x 64).
+// Set bits of 64 ballots (lane r holds row r, rowbase = bits set in earlier rows) -> ascending
+// list in LDS.  Every lane walks its own row: work is O(set bits), not O(rows x 64).
 __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, unsigned rowbase, int lane, unsigned short *lst)
 {
-    const int r = lane & 31, hi = lane >> 5;
-    const unsigned long long bits = lpf_rl64_var(rowbits, r);
-    const unsigned base = (unsigned)__shfl((int)rowbase, r);
-    unsigned half = hi ? (unsigned)(bits >> 32) : (unsigned)bits;
-    unsigned pos = base + (hi ? __popc((unsigned)bits) : 0u);
-    const unsigned short tag = (unsigned short)(r * 64 + hi * 32);
-    while (half) {
-        const int b = __ffs(half) - 1;
-        half &= half - 1;
+    unsigned pos = rowbase;
+    const unsigned short tag = (unsigned short)(lane * 64);
+    while (rowbits) {
+        const int b = __ffsll((long long)rowbits) - 1;
+        rowbits &= rowbits - 1ull;
         lst[pos++] = (unsigned short)(tag + b);
     }
 }
@@ -484,6 +499,9 @@ __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, uns
 #define LPF_F2_LAB_NOLIST 2u      // stop after valid_idx
 #define LPF_F2_LAB_NOBOX 4u
 #define LPF_F2_LAB_NOINST 8u
+#define LPF_F2_LAB_NOEXACT 16u
+#define LPF_F2_LAB_NOCAND 32u
+#define LPF_F2_LAB_NOPROJ 64u
 
 template <unsigned FL2>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
@@ -491,6 +509,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // valid, then masked points (segment-relative)
     __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz of the current 64 masked points
     __shared__ float4 s_bq[LPF_K2_WAVES][2 * 64];                      // {lo, hi} of the current <= 64 boxes
+    __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds
     const int lane = lpf_lane(), wave = lpf_wave();
     const int sid = blockIdx.x * LPF_K2_WAVES + wave;
     if (sid >= P.nseg_total) return;
@@ -500,10 +519,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     const int ngroups = (2 + P.M + 3) >> 2;
     unsigned long long vb = 0, mb = 0;
     uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < LPF_K2_ROWS) {
-        vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
-        mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
-    }
+    vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
+    mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
     if (lane < ngroups) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
 
     const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     const unsigned cv = __popcll(vb), cm = __popcll(mb);
     unsigned iv = cv, im = cm;
 #pragma unroll
-    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {            // inclusive scan over the 32 row counts
+    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {            // inclusive scan over the 64 row counts
         const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
         if (lane >= o) { iv += tv; im += tm; }
     }
@@ -547,19 +564,27 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
         const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
         posreg = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
     }
-    const float4 *__restrict__ pts = P.pts + fr.pt_off;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
     unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
+    // the same order as the set bits of the masked ballots: entry e of the segment, found in
+    // row r, is entry e - mbase[first row of r's K1 wave] of that wave.  No gather from the cloud,
+    // the label array or (u, v).
+    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+    const int rows_per_wave = P.tile_pts >> 8;              // K1 tile = 4 waves of tile_pts/4 points
 
     for (unsigned e0 = 0; e0 < L; e0 += 64) {
-        // ---- round trip 2: labels + xyz of up to 64 masked points, box bounds in lanes ---------
+        // ---- round trip 2: the tile lists (coalesced) and the box bounds ---------------------
         const unsigned e = e0 + lane;
         const bool act = e < L;
-        const unsigned idx = (unsigned)seg_start + (unsigned)lst[act ? e : 0];
-        const unsigned lab = act ? P.label_bits[fr.pt_off + idx] : 0u;
         float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (do_box && act) pq = pts[idx];
+        const unsigned li = lst[act ? e : 0];                // segment-relative point index
+        const int first_row = ((int)(li >> 6) / rows_per_wave) * rows_per_wave;
+        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);            // all lanes take part
+        if (act) pq = mseg[first_row * 64 + (int)(e - wb)];
+        const unsigned idx = (unsigned)seg_start + li;
+        const unsigned lab = __float_as_uint(pq.w);
         float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
         if (do_box && lane < B) { blo = boxq[2 * lane]; bhi = boxq[2 * lane + 1]; }
 
@@ -577,45 +602,73 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
                 if (lane == m) posreg += (unsigned)__popcll(bal);
             }
         }
-        // ---- K6: (masked point, box) pairs spread over the lanes: 64 points x <= 64 boxes per
-        //      round, both sides staged in this wave's LDS; a conservative float AABB of the
-        //      accepted region rejects most pairs, the survivors take the reference's f64 test ----
+        // ---- K6: lane = masked point.  The frame's candidate grid (built with the boxes) lists, per
+        //      32x32-pixel cell, the boxes whose accepted region can project there; a point only
+        //      meets those.  Candidates pass a conservative float AABB of the region first, the
+        //      survivors are queued and take the reference's f64 test a whole wave at a time. ------
         if (do_box) {
-            const int nact = min(64, (int)(L - e0));
             __builtin_amdgcn_wave_barrier();
             s_pt[wave][lane] = make_float4(pq.x, pq.y, pq.z, __uint_as_float(lab));   // .w carries the label bits
-            for (int b0 = 0; b0 < B; b0 += 64) {
-                const int nb = min(B - b0, 64);
-                if (b0 > 0) {                               // B > 64: next 64 boxes' bounds
-                    blo = bhi = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (lane < nb) { blo = boxq[2 * (b0 + lane)]; bhi = boxq[2 * (b0 + lane) + 1]; }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                s_bq[wave][2 * lane] = blo; s_bq[wave][2 * lane + 1] = bhi;
-                __builtin_amdgcn_wave_barrier();
-                int sh = 0;                                 // boxes padded to a power of two: pair -> (point, box) by shift/mask
-                while ((1 << sh) < nb) ++sh;
-                const int npair = nact << sh;
-                for (int p0 = 0; p0 < npair; p0 += 64) {
-                    const int p = p0 + lane, e = p >> sh, b = p & ((1 << sh) - 1);
-                    if (p < npair && b < nb) {
-                        const float4 x = s_pt[wave][e], lo = s_bq[wave][2 * b], hi = s_bq[wave][2 * b + 1];
-                        if (x.x >= lo.x && x.x <= hi.x && x.y >= lo.y && x.y <= hi.y && x.z >= lo.z && x.z <= hi.z) {
-                            const double *bp = boxp + (size_t)(b0 + b) * 16;
-                            const bool in = P.oriented ? lpf_oriented_inside((double)x.x, (double)x.y, (double)x.z, bp)
-                                                       : lpf_aabb_inside((double)x.x, (double)x.y, (double)x.z, bp);
-                            if (in) {
-                                unsigned l = __float_as_uint(x.w);
-                                while (l) {
-                                    const int m = __ffs(l) - 1;
-                                    l &= l - 1;
-                                    atomicAdd(&cnt[m * B + b0 + b], 1u);
-                                }
-                            }
+            s_bq[wave][2 * lane] = blo; s_bq[wave][2 * lane + 1] = bhi;               // bounds of boxes 0..63
+            __builtin_amdgcn_wave_barrier();
+            unsigned *qq = s_q[wave];
+            int qn = 0;                                     // wave-uniform queue length
+            auto exact = [&](int count) {
+                if (lane < count && !(FL2 & LPF_F2_LAB_NOEXACT)) {
+                    const unsigned ent = qq[lane];
+                    const int e = (int)(ent & 63u), b = (int)(ent >> 6);
+                    const float4 x = s_pt[wave][e];
+                    const double *bp = boxp + (size_t)b * 16;
+                    const bool in = P.oriented ? lpf_oriented_inside((double)x.x, (double)x.y, (double)x.z, bp)
+                                               : lpf_aabb_inside((double)x.x, (double)x.y, (double)x.z, bp);
+                    if (in) {
+                        unsigned l = __float_as_uint(x.w);
+                        while (l) {
+                            const int m = __ffs(l) - 1;
+                            l &= l - 1;
+                            atomicAdd(&cnt[m * B + b], 1u);
                         }
                     }
                 }
+            };
+            int cell = 0;
+            if (act && !(FL2 & LPF_F2_LAB_NOPROJ)) {        // same arithmetic as K1 => the same pixel; valid => in range
+                double uf, vf, d;
+                lpf_project_point(P, pq.x, pq.y, pq.z, uf, vf, d);
+                cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
             }
+            const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
+            for (int w = 0; w < fr.cand_words; ++w) {
+                unsigned long long mset = (act && !(FL2 & LPF_F2_LAB_NOCAND)) ? cg[w] : 0ull;
+                while (__any(mset != 0ull)) {
+                    const bool has = mset != 0ull;
+                    const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
+                    mset &= mset - 1ull;
+                    bool near = false;
+                    if (has) {
+                        float4 lo, hi;
+                        if (b < 64) { lo = s_bq[wave][2 * b]; hi = s_bq[wave][2 * b + 1]; }
+                        else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
+                        near = pq.x >= lo.x && pq.x <= hi.x && pq.y >= lo.y && pq.y <= hi.y && pq.z >= lo.z && pq.z <= hi.z;
+                    }
+                    const unsigned long long bal = __ballot(near);
+                    if (!bal) continue;
+                    if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
+                    qn += __popcll(bal);
+                    if (qn >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        exact(64);
+                        const unsigned t = qq[64 + lane];
+                        __builtin_amdgcn_wave_barrier();
+                        qq[lane] = t;
+                        qn -= 64;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            exact(qn);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -123,15 +123,18 @@ int main(int argc, char **argv)
         CK(hipMemset(cnt, 0, 8 * 32 * 4));
         CK(hipMalloc(&vidx, (size_t)N * 8)); CK(hipMalloc(&iidx, (size_t)N * 8));
         std::vector<double> hbp(32 * 16, 0.0); std::vector<float> hbq(32 * 8, 0.f);
-        for (int b = 0; b < 32; ++b) {   // axis-aligned 4 m cubes in front of the sensor
-            double *o = &hbp[b * 16]; const double cx = 5 + (b % 8) * 5, cy = -20 + (b / 8) * 10, cz = -2;
-            o[0] = cx; o[1] = cy; o[2] = cz; o[3] = 4; o[6] = 16; o[8] = 4; o[10] = 16; o[13] = 4; o[14] = 16; o[15] = 1;
-            float *q = &hbq[b * 8]; q[0] = cx - 0.1f; q[1] = cy - 0.1f; q[2] = cz - 0.1f; q[4] = cx + 4.1f; q[5] = cy + 4.1f; q[6] = cz + 4.1f;
+        for (int b = 0; b < 32; ++b) {   // axis-aligned car-sized boxes (4.4 x 2.0 x 1.65 m) inside the frustum
+            double *o = &hbp[b * 16]; const double cx = 6 + (b % 8) * 5, cy = -12 + (b / 8) * 7, cz = -1.8;
+            o[0] = cx; o[1] = cy; o[2] = cz; o[3] = 4.4; o[6] = 4.4 * 4.4; o[8] = 2.0; o[10] = 4.0; o[13] = 1.65; o[14] = 1.65 * 1.65; o[15] = 1;
+            float *q = &hbq[b * 8]; q[0] = cx - 0.01f; q[1] = cy - 0.01f; q[2] = cz - 0.01f; q[4] = cx + 4.41f; q[5] = cy + 2.01f; q[6] = cz + 1.66f;
         }
         CK(hipMalloc(&boxp, hbp.size() * 8)); CK(hipMalloc(&boxq, hbq.size() * 4));
         CK(hipMemcpy(boxp, hbp.data(), hbp.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(boxq, hbq.data(), hbq.size() * 4, hipMemcpyHostToDevice));
+        unsigned long long *cand; { std::vector<unsigned long long> hc(44 * 12, 0xFFFFFFFFull); CK(hipMalloc(&cand, hc.size() * 8)); CK(hipMemcpy(cand, hc.data(), hc.size() * 8, hipMemcpyHostToDevice)); }
+        fr.cand_off = 0; fr.cand_words = 1; P.cand = cand; P.cell_shift = 5; P.cell_w = 44;
         P.seg_pts = seg_pts; P.nseg_total = nseg; P.nseg_cap = nseg; P.frame0 = fr; P.oriented = 1;
         P.seg_pre = pre; P.frame_tot = ftot; P.cnt = cnt; P.valid_idx = vidx; P.inst_idx = iidx; P.inst_cap = N; P.boxp = boxp; P.boxq = boxq;
+        float4 *ml; CK(hipMalloc(&ml, (size_t)N * 16)); P.mlist = ml; P.tile_pts = 1024;
         P.pts = pts[0]; P.uv = uv[0]; P.label_bits = lab[0];
         launch_t<4, LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE>(P, nseg, s);
         CK(hipStreamSynchronize(s));
