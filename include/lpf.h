@@ -86,6 +86,11 @@ const char *lpf_last_error(const lpf_ctx *ctx);      /* ctx may be NULL: error o
 /* Run on a stream the caller owns (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
 int  lpf_set_stream(lpf_ctx *ctx, void *hip_stream);
 int  lpf_sync(lpf_ctx *ctx);
+/* Pipelined device-mode runs: the short tail kernels of a run (segment scan, list building,
+ * per-frame summary) execute on a second, internal stream and overlap the streaming kernel of
+ * the next run, which uses a second set of scratch buffers.  With it on, the outputs of a run are
+ * complete after lpf_sync(), not after the caller's stream alone.  Off by default. */
+int  lpf_set_pipelined(lpf_ctx *ctx, int on);
 
 /* ---- per-sequence state --------------------------------------------------------
  * Replaces V3:565-569 + V3:584 constants.  T = TrVeloToRect (row-major 4x4, V3:535),

@@ -67,6 +67,7 @@ def load():
     lib.lpf_destroy.restype = None
     lib.lpf_set_stream.argtypes = [_P, _P]
     lib.lpf_sync.argtypes = [_P]
+    lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -82,7 +83,7 @@ def load():
     return lib
 
 
-EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync",
+EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_profile_enable", "lpf_profile_read")
@@ -146,6 +147,11 @@ class LpfContext:
 
     def sync(self):
         self._check(self._lib.lpf_sync(self._h))
+
+    def set_pipelined(self, on=True):
+        """Tail kernels of a device-mode run on a second stream (overlap with the next run); results
+        of a run are then complete after sync()."""
+        self._check(self._lib.lpf_set_pipelined(self._h, int(bool(on))))
 
     def profile_enable(self, on=True):
         self._check(self._lib.lpf_profile_enable(self._h, int(bool(on))))

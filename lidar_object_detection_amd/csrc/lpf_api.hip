@@ -53,7 +53,17 @@ struct lpf_ctx {
     bool cand_dirty = true;
 
     // per-run scratch
-    DevBuf frames, segs, vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
+    DevBuf frames, segs;
+    // Scratch of one in-flight run.  Two sets: with pipelining on, the tail kernels of run i (second
+    // stream) overlap the streaming kernel of run i+1 (caller's stream), which uses the other set.
+    struct Scratch {
+        DevBuf vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
+        hipEvent_t k1_done = nullptr, tail_done = nullptr;
+        bool tail_pending = false;
+    } sc[2];
+    int parity = 0;
+    bool pipelined = false;
+    hipStream_t stream_b = nullptr;   // created on first pipelined run
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
@@ -87,13 +97,22 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                     \
     } while (0)
 
+int sync_all(lpf_ctx *c)                // both streams idle: shared tables / buffers may be rewritten
+{
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->stream_b) LPF_HIP(c, hipStreamSynchronize(c->stream_b));
+    for (auto &S : c->sc) S.tail_pending = false;
+    return LPF_OK;
+}
+
 // grow-only; new memory is zeroed (the self-cleaning counters rely on it)
 int reserve(lpf_ctx *c, DevBuf &b, size_t bytes, bool zero = false)
 {
     if (bytes <= b.cap && b.p) return LPF_OK;
     if (bytes == 0) bytes = 256;
     if (b.p) {
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        int rc_ = sync_all(c);
+        if (rc_) return rc_;
         LPF_HIP(c, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
     }
@@ -246,6 +265,7 @@ int build_candidates(lpf_ctx *c, int F)
         }
     }
     int rc;
+    if ((rc = sync_all(c))) return rc;
     if ((rc = reserve(c, c->cand, g.size() * 8))) return rc;
     LPF_HIP(c, hipMemcpyAsync(c->cand.p, g.data(), g.size() * 8, hipMemcpyHostToDevice, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));          // g is a local
@@ -349,8 +369,15 @@ void lpf_destroy(lpf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->vbal, &c->mbal,
-                     &c->seg_tab, &c->seg_pre, &c->frame_tot, &c->segs, &c->cnt, &c->mlist, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+    for (auto &S : c->sc) {
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.seg_pre, &S.frame_tot, &S.cnt, &S.mlist};
+        for (DevBuf *b : sb) release(*b);
+        if (S.k1_done) (void)hipEventDestroy(S.k1_done);
+        if (S.tail_done) (void)hipEventDestroy(S.tail_done);
+    }
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
+    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -364,7 +391,7 @@ int lpf_set_stream(lpf_ctx *c, void *s)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (s) {
         c->stream = (hipStream_t)s;
@@ -379,7 +406,24 @@ int lpf_sync(lpf_ctx *c)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    return sync_all(c);
+}
+
+int lpf_set_pipelined(lpf_ctx *c, int on)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    if (on && !c->stream_b) LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    for (auto &S : c->sc) {
+        if (on && !S.k1_done) {
+            LPF_HIP(c, hipEventCreateWithFlags(&S.k1_done, hipEventDisableTiming));
+            LPF_HIP(c, hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
+        }
+    }
+    c->pipelined = on != 0;
+    c->parity = 0;
     return LPF_OK;
 }
 
@@ -442,6 +486,7 @@ int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int
     if (use_device(c)) return LPF_ERR_HIP;
     if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "set_boxes: F=%d box_off=%p", F, (const void *)box_off);
     c->box_F = 0; c->box_off.clear();
+    { int rc_ = sync_all(c); if (rc_) return rc_; }       // the tail kernels of a pending run may still read the tables
     if (F == 0) return LPF_OK;
     if (box_off[0] != 0) return fail(c, LPF_ERR_ARG, "set_boxes: box_off[0] must be 0");
     for (int f = 0; f < F; ++f)
@@ -513,14 +558,19 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const int nseg_cap = nseg_total > 0 ? nseg_total : 1;
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
 
+    // pipelined device runs alternate between two scratch sets; everything else uses set 0 with both streams idle
+    const bool pipe = c->pipelined && !host_io && pts_on_device;
+    if (!pipe && c->stream_b && (rc = sync_all(c))) return rc;
+    lpf_ctx::Scratch &S = c->sc[pipe ? c->parity : 0];
+    hipStream_t tail_stream = pipe ? c->stream_b : c->stream;
     if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
-    if ((rc = reserve(c, c->vbal, rows * 8))) return rc;
-    if ((rc = reserve(c, c->mbal, rows * 8))) return rc;
-    if ((rc = reserve(c, c->seg_tab, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4), true))) return rc;
-    if ((rc = reserve(c, c->seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
-    if ((rc = reserve(c, c->frame_tot, (size_t)F * LPF_TAB_ROWS * 4))) return rc;
+    if ((rc = reserve(c, S.vbal, rows * 8))) return rc;
+    if ((rc = reserve(c, S.mbal, rows * 8))) return rc;
+    if ((rc = reserve(c, S.seg_tab, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4), true))) return rc;
+    if ((rc = reserve(c, S.seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
+    if ((rc = reserve(c, S.frame_tot, (size_t)F * LPF_TAB_ROWS * 4))) return rc;
     if (F > 1 && (rc = reserve(c, c->segs, (size_t)nseg_cap * sizeof(LpfFrame)))) return rc;
-    if ((rc = reserve(c, c->cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
+    if ((rc = reserve(c, S.cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
 
     LpfParams P;
     memset(&P, 0, sizeof P);
@@ -533,9 +583,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.label_img = (M > 0) ? c->label_cur : nullptr;
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
-    P.vbal = (unsigned long long *)c->vbal.p; P.mbal = (unsigned long long *)c->mbal.p;
-    P.seg_tab = (uint4 *)c->seg_tab.p; P.seg_pre = (uint4 *)c->seg_pre.p; P.frame_tot = (unsigned *)c->frame_tot.p;
-    P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)c->cnt.p;
+    P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
+    P.seg_tab = (uint4 *)S.seg_tab.p; P.seg_pre = (uint4 *)S.seg_pre.p; P.frame_tot = (unsigned *)S.frame_tot.p;
+    P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -572,14 +622,15 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     }
 #undef LPF_OUTBUF
     if (M > 0) {                         // K1 -> K2 hand-off of the masked points (sparse writes into N slots)
-        if ((rc = reserve(c, c->mlist, n * 16))) return rc;
-        P.mlist = (float4 *)c->mlist.p;
+        if ((rc = reserve(c, S.mlist, n * 16))) return rc;
+        P.mlist = (float4 *)S.mlist.p;
     }
 
     // The frame table only changes when the batch geometry does; upload it then (and wait, the
     // source is pageable host memory that the next call rewrites).
     if (c->h_frames_dev.size() != c->h_frames.size() ||
         memcmp(c->h_frames_dev.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) != 0) {
+        if ((rc = sync_all(c))) return rc;                 // a pending tail may still read the old tables
         LPF_HIP(c, hipMemcpyAsync(c->frames.p, c->h_frames.data(), (size_t)F * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
         if (F > 1) {                                      // per-segment copy of the owning frame's record
             c->h_segs.resize((size_t)nseg_total);
@@ -591,6 +642,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipStreamSynchronize(c->stream));
         c->h_frames_dev = c->h_frames;
     }
+    if (pipe && S.tail_pending) LPF_HIP(c, hipStreamWaitEvent(c->stream, S.tail_done, 0));   // this set's previous tail
     if (nseg_total > 0) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->profiling && c->ev_used < (1u << 16)) {
@@ -613,31 +665,40 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
     }
+    if (pipe) {                                            // hand over to the second stream
+        LPF_HIP(c, hipEventRecord(S.k1_done, c->stream));
+        LPF_HIP(c, hipStreamWaitEvent(tail_stream, S.k1_done, 0));
+    }
     {
         int max_nseg = 0;
         for (int f = 0; f < F; ++f) if (c->h_frames[f].nseg > max_nseg) max_nseg = c->h_frames[f].nseg;
         if (max_nseg <= 4 * LPF_BLOCK && (2 + M + 3) / 4 <= 3)          // <= 1024 segments per frame, M <= 10
-            hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+            hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
         else
-            hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+            hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
         LPF_HIP(c, hipGetLastError());
     }
     if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
         const dim3 g2((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES);
         static const int k2_ablate = getenv("LPF_DEV_K2_ABLATE") ? atoi(getenv("LPF_DEV_K2_ABLATE")) : 0;   // profiling aid only
-        if (k2_ablate == 4) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 8) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 2) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 16) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOEXACT>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 32) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 96) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND | LPF_F2_LAB_NOPROJ>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else if (k2_ablate == 12) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, c->stream, P);
-        else hipLaunchKernelGGL((lpf_k2_lists), g2, dim3(LPF_BLOCK), 0, c->stream, P);
+        if (k2_ablate == 4) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 8) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 2) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 16) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOEXACT>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 32) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 96) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND | LPF_F2_LAB_NOPROJ>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (k2_ablate == 12) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else hipLaunchKernelGGL((lpf_k2_lists), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         LPF_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
     LPF_HIP(c, hipGetLastError());
 
+    if (pipe) {
+        LPF_HIP(c, hipEventRecord(S.tail_done, tail_stream));
+        S.tail_pending = true;
+        c->parity ^= 1;
+    }
     if (host_io) {
 #define LPF_D2H(member, field, bytes) \
     if (out->member && (bytes)) LPF_HIP(c, hipMemcpyAsync(out->member, P.field, (bytes), hipMemcpyDeviceToHost, c->stream));

@@ -274,3 +274,59 @@ def test_full_size_properties_2m(ctx, calib):
     lab = orc.pack_masks(sc["masks"], 0, H, W)
     o = orc.run(sc["points"], T, K, W, H, 0.0, 30.0, label_img=lab, M=8, corners=sc["corners_velo"], want_float=False)
     _compare(r, o, 8, want_float=False)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_device_mode_back_to_back_runs(calib, pipelined):
+    """Device-pointer mode (torch tensors): several different batches enqueued back to back without
+    host syncs, with and without the tail kernels on a second stream; every run must equal the oracle."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    ctx = LpfContext(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_pipelined(pipelined)
+    ctx.set_camera(T, K, W, H, 0.0, 30.0)
+    F, M, Bx = 3, 5, 7
+    runs = []
+    for k in range(6):
+        sizes = [30000 + 4097 * k, 1 + k, 70000 - 5000 * k]
+        scenes = [S.scene(n, n_masks=M, n_boxes=Bx, seed=100 * k + f) for f, n in enumerate(sizes)]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        pts = torch.from_numpy(np.concatenate([sc["points"] for sc in scenes])).to(dev)
+        masks = torch.from_numpy(np.stack([sc["masks"] for sc in scenes])).to(dev)
+        n = int(off[-1])
+        o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                 valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, n), dtype=torch.int64, device=dev),
+                 count_mb=torch.zeros(F * M * Bx, dtype=torch.int32, device=dev),
+                 summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        runs.append((scenes, sizes, off, pts, masks, o))
+    ctx.set_boxes([sc["corners_velo"] for sc in runs[0][0]])       # same boxes for every run (tables are per context)
+    torch.cuda.synchronize(dev)
+    for scenes, sizes, off, pts, masks, o in runs:
+        ctx.set_masks(masks)
+        ctx.run_device(pts, off, inst_cap=int(off[-1]), **o)
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    for scenes, sizes, off, pts, masks, o in runs:
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+        uv, lab = o["uv"].cpu().numpy(), o["label_bits"].cpu().numpy().view(np.uint32)
+        vidx, iidx, cmb = o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy(), o["count_mb"].cpu().numpy()
+        for f, (sc, nf) in enumerate(zip(scenes, sizes)):
+            a, b = int(off[f]), int(off[f + 1])
+            limg = orc.pack_masks(sc["masks"], 0, H, W)
+            ref = orc.run(sc["points"][:nf], T, K, W, H, 0.0, 30.0, label_img=limg, M=M, corners=runs[0][0][f]["corners_velo"],
+                          want_float=False)
+            assert np.array_equal(uv[a:b, 0], ref["u"]) and np.array_equal(uv[a:b, 1], ref["v"])
+            assert np.array_equal(lab[a:b], ref["label_bits"])
+            assert int(sm[f]["n_valid"]) == ref["n_valid"]
+            assert np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"])
+            assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"])
+            for m in range(M):
+                lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+                assert np.array_equal(iidx[f, lo:hi], ref["inst_lists"][m])
+            assert np.array_equal(cmb[M * Bx * f:M * Bx * (f + 1)].reshape(M, Bx), ref["count_mb"])
+            assert np.array_equal(sm[f]["best_box"][:M], ref["best_box"]) and np.array_equal(sm[f]["best_cnt"][:M], ref["best_cnt"])
+    ctx.close()
