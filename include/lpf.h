@@ -138,6 +138,19 @@ int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int 
 int lpf_points_in_boxes(lpf_ctx *ctx, const float *pts, int64_t k, int stride, const double *corners_velo,
                         int B, int oriented, uint8_t *inside, int on_device);
 
+/* ---- hipGraph capture of a launch set ------------------------------------------------------
+ * lpf_graph_begin puts the context's stream into capture mode; every device-mode lpf_set_masks_* /
+ * lpf_run* call issued until lpf_graph_end is recorded instead of executed (pointers and sizes are
+ * baked in; the caller may add its own async copies on the same stream in between).  lpf_graph_end
+ * instantiates the graph; lpf_graph_launch replays it on the context's stream.  The context must
+ * have run the same shapes once before capture (so no allocation or table upload happens inside
+ * it), and pipelining must be off.  For launch-bound per-frame loops (10 Hz streaming). */
+typedef struct lpf_graph lpf_graph;
+int  lpf_graph_begin(lpf_ctx *ctx);
+int  lpf_graph_end(lpf_ctx *ctx, lpf_graph **out);
+int  lpf_graph_launch(lpf_ctx *ctx, lpf_graph *g);
+void lpf_graph_destroy(lpf_graph *g);
+
 /* ---- measurement -------------------------------------------------------------------
  * With profiling on, every lpf_run* brackets its project+label kernel (lpf_k1_project, the
  * dominant kernel) with HIP events on the context's stream.  lpf_profile_read waits for the

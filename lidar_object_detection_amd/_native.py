@@ -77,6 +77,11 @@ def load():
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
+    lib.lpf_graph_begin.argtypes = [_P]
+    lib.lpf_graph_end.argtypes = [_P, ctypes.POINTER(_P)]
+    lib.lpf_graph_launch.argtypes = [_P, _P]
+    lib.lpf_graph_destroy.argtypes = [_P]
+    lib.lpf_graph_destroy.restype = None
     lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
     lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
     _lib = lib
@@ -86,7 +91,8 @@ def load():
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_profile_enable", "lpf_profile_read")
+            "lpf_points_in_boxes", "lpf_profile_enable", "lpf_profile_read",
+            "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy")
 
 
 def _is_torch(x):
@@ -152,6 +158,22 @@ class LpfContext:
         """Tail kernels of a device-mode run on a second stream (overlap with the next run); results
         of a run are then complete after sync()."""
         self._check(self._lib.lpf_set_pipelined(self._h, int(bool(on))))
+
+    def graph_begin(self):
+        """Start capturing the device-mode calls made on this context into a hipGraph."""
+        self._check(self._lib.lpf_graph_begin(self._h))
+
+    def graph_end(self):
+        """Finish the capture; returns an opaque handle for graph_launch()."""
+        g = _P()
+        self._check(self._lib.lpf_graph_end(self._h, ctypes.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        self._check(self._lib.lpf_graph_launch(self._h, g))
+
+    def graph_destroy(self, g):
+        self._lib.lpf_graph_destroy(g)
 
     def profile_enable(self, on=True):
         self._check(self._lib.lpf_profile_enable(self._h, int(bool(on))))

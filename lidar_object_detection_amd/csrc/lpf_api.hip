@@ -25,7 +25,13 @@ struct DevBuf {                       // grow-only device buffer
 
 }  // namespace
 
+struct lpf_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct lpf_ctx {
+    bool capturing = false;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -99,6 +105,9 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
 
 int sync_all(lpf_ctx *c)                // both streams idle: shared tables / buffers may be rewritten
 {
+    if (c->capturing)
+        return fail(c, LPF_ERR_STATE, "this call needs a synchronisation or (re)allocation, which cannot be captured into a graph: "
+                                      "run the same shapes once before lpf_graph_begin");
     LPF_HIP(c, hipStreamSynchronize(c->stream));
     if (c->stream_b) LPF_HIP(c, hipStreamSynchronize(c->stream_b));
     for (auto &S : c->sc) S.tail_pending = false;
@@ -109,6 +118,7 @@ int sync_all(lpf_ctx *c)                // both streams idle: shared tables / bu
 int reserve(lpf_ctx *c, DevBuf &b, size_t bytes, bool zero = false)
 {
     if (bytes <= b.cap && b.p) return LPF_OK;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "allocation inside graph capture: run the same shapes once before lpf_graph_begin");
     if (bytes == 0) bytes = 256;
     if (b.p) {
         int rc_ = sync_all(c);
@@ -560,7 +570,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 
     // pipelined device runs alternate between two scratch sets; everything else uses set 0 with both streams idle
     const bool pipe = c->pipelined && !host_io && pts_on_device;
-    if (!pipe && c->stream_b && (rc = sync_all(c))) return rc;
+    if (!pipe && c->stream_b && (c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c))) return rc;
     lpf_ctx::Scratch &S = c->sc[pipe ? c->parity : 0];
     hipStream_t tail_stream = pipe ? c->stream_b : c->stream;
     if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
@@ -758,6 +768,55 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
     if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));           // bp is a local
     return LPF_OK;
+}
+
+int lpf_graph_begin(lpf_ctx *c)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (c->pipelined) return fail(c, LPF_ERR_STATE, "graph capture needs pipelining off");
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "already capturing");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    LPF_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return LPF_OK;
+}
+
+int lpf_graph_end(lpf_ctx *c, lpf_graph **out)
+{
+    if (!c || !out) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->capturing) return fail(c, LPF_ERR_STATE, "lpf_graph_end without lpf_graph_begin");
+    c->capturing = false;
+    lpf_graph *g = new (std::nothrow) lpf_graph();
+    if (!g) return fail(c, LPF_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return fail(c, LPF_ERR_HIP, "graph capture failed: %s (a call inside the capture allocated, copied from pageable memory or synchronised?)",
+                    hipGetErrorString(e));
+    }
+    *out = g;
+    return LPF_OK;
+}
+
+int lpf_graph_launch(lpf_ctx *c, lpf_graph *g)
+{
+    if (!c || !g || !g->exec) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    LPF_HIP(c, hipGraphLaunch(g->exec, c->stream));
+    return LPF_OK;
+}
+
+void lpf_graph_destroy(lpf_graph *g)
+{
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
 }
 
 int lpf_profile_enable(lpf_ctx *c, int on)
