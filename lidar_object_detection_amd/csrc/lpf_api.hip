@@ -43,8 +43,6 @@ struct lpf_ctx {
 
     // masks -> label images
     int mask_F = 0, mask_M = 0;       // 0 frames = no masks set
-    DevBuf label_a, label_b;          // [F][H][W] uint32 (b = erosion ping-pong)
-    uint32_t *label_cur = nullptr;
     DevBuf mask_stage;
 
     // boxes
@@ -64,12 +62,15 @@ struct lpf_ctx {
     // stream) overlap the streaming kernel of run i+1 (caller's stream), which uses the other set.
     struct Scratch {
         DevBuf vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
-        hipEvent_t k1_done = nullptr, tail_done = nullptr;
-        bool tail_pending = false;
+        DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
+        uint32_t *label_cur = nullptr;
+        hipEvent_t k1_done = nullptr, tail_done = nullptr, mask_done = nullptr;
+        bool tail_pending = false, k1_recorded = false, mask_pending = false;
     } sc[2];
     int parity = 0;
     bool pipelined = false;
-    hipStream_t stream_b = nullptr;   // created on first pipelined run
+    hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
+    hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
@@ -110,7 +111,8 @@ int sync_all(lpf_ctx *c)                // both streams idle: shared tables / bu
                                       "run the same shapes once before lpf_graph_begin");
     LPF_HIP(c, hipStreamSynchronize(c->stream));
     if (c->stream_b) LPF_HIP(c, hipStreamSynchronize(c->stream_b));
-    for (auto &S : c->sc) S.tail_pending = false;
+    if (c->stream_c) LPF_HIP(c, hipStreamSynchronize(c->stream_c));
+    for (auto &S : c->sc) { S.tail_pending = false; S.k1_recorded = false; S.mask_pending = false; }
     return LPF_OK;
 }
 
@@ -291,11 +293,24 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called before masks (W, H)");
     if (F < 0 || M < 0 || M > LPF_MAX_MASKS || erode_iters < 0 || (F > 0 && M > 0 && !masks))
         return fail(c, LPF_ERR_ARG, "set_masks: F=%d M=%d erode_iters=%d masks=%p", F, M, erode_iters, (const void *)masks);
-    c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr;
+    // Pipelined + device masks: pack on the third stream into the label buffers of the scratch set
+    // the next run will use, so it overlaps the current run's streaming kernel.
+    // (Measured: packing on a side stream competes with the streaming kernel for HBM and lowers
+    //  both the step rate and that kernel's bandwidth -- 136 vs 142 Gpoints/s -- so the pack stays on
+    //  the caller's stream; the per-set label buffers keep the option open.)
+    const bool side = false;
+    const bool pipe = side && c->pipelined && on_device && !c->capturing;
+    const bool per_set = c->pipelined && on_device && !c->capturing;
+    int rc;
+    if (!per_set && (c->stream_b || c->stream_c) && (c->sc[0].tail_pending || c->sc[1].tail_pending || c->sc[0].mask_pending ||
+                                                      c->sc[1].mask_pending) && (rc = sync_all(c))) return rc;
+    lpf_ctx::Scratch &S = c->sc[per_set ? c->parity : 0];
+    hipStream_t ms = pipe ? c->stream_c : c->stream;
+    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr;
     if (F == 0) return LPF_OK;
     const size_t hw = (size_t)c->H * c->W;
-    int rc;
-    if ((rc = reserve(c, c->label_a, (size_t)F * hw * 4))) return rc;
+    if ((rc = reserve(c, S.label_a, (size_t)F * hw * 4))) return rc;
+    if (pipe && S.k1_recorded) LPF_HIP(c, hipStreamWaitEvent(ms, S.k1_done, 0));   // the set's previous K1 still reads its label image
     const T *d_masks = masks;
     if (M > 0 && !on_device) {
         const size_t bytes = (size_t)F * M * hw * sizeof(T);
@@ -304,9 +319,9 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         d_masks = (const T *)c->mask_stage.p;
     }
     dim3 grid((c->W + LPF_TW - 1) / LPF_TW, (c->H + LPF_TH - 1) / LPF_TH, F);
-    uint32_t *cur = (uint32_t *)c->label_a.p;
+    uint32_t *cur = (uint32_t *)S.label_a.p;
     if (M == 0) {
-        LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * 4, c->stream));
+        LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * 4, ms));
     } else {
         int left = erode_iters;
         if (hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
@@ -314,34 +329,35 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
             const long long total16 = (long long)F * (long long)(hw / 16);
             const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
             if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack16<T, 0>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 0>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
             else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack16<T, 1>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 1>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
             else
-                hipLaunchKernelGGL((lpf_pack16<T, 2>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 2>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
         } else {
             const int fuse = erode_iters > 0 ? 1 : 0;
             left -= fuse;
             if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
             else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
             else
-                hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, c->stream, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
         }
         LPF_HIP(c, hipGetLastError());
         if (left > 0) {
-            if ((rc = reserve(c, c->label_b, (size_t)F * hw * 4))) return rc;
-            uint32_t *other = (uint32_t *)c->label_b.p;
+            if ((rc = reserve(c, S.label_b, (size_t)F * hw * 4))) return rc;
+            uint32_t *other = (uint32_t *)S.label_b.p;
             for (int it = 0; it < left; ++it) {
-                hipLaunchKernelGGL(lpf_erode_packed, grid, dim3(LPF_BLOCK), 0, c->stream, cur, other, c->H, c->W);
+                hipLaunchKernelGGL(lpf_erode_packed, grid, dim3(LPF_BLOCK), 0, ms, cur, other, c->H, c->W);
                 LPF_HIP(c, hipGetLastError());
                 uint32_t *t = cur; cur = other; other = t;
             }
         }
     }
     if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
-    c->label_cur = cur;
+    if (pipe) { LPF_HIP(c, hipEventRecord(S.mask_done, ms)); S.mask_pending = true; }
+    S.label_cur = cur;
     c->mask_F = F; c->mask_M = M;
     return LPF_OK;
 }
@@ -380,14 +396,17 @@ void lpf_destroy(lpf_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+    if (c->stream_c) (void)hipStreamSynchronize(c->stream_c);
     for (auto &S : c->sc) {
-        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.seg_pre, &S.frame_tot, &S.cnt, &S.mlist};
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.seg_pre, &S.frame_tot, &S.cnt, &S.mlist, &S.label_a, &S.label_b};
         for (DevBuf *b : sb) release(*b);
         if (S.k1_done) (void)hipEventDestroy(S.k1_done);
         if (S.tail_done) (void)hipEventDestroy(S.tail_done);
+        if (S.mask_done) (void)hipEventDestroy(S.mask_done);
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
-    DevBuf *all[] = {&c->label_a, &c->label_b, &c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
+    if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -426,10 +445,12 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
     int rc = sync_all(c);
     if (rc) return rc;
     if (on && !c->stream_b) LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    if (on && !c->stream_c) LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
     for (auto &S : c->sc) {
         if (on && !S.k1_done) {
             LPF_HIP(c, hipEventCreateWithFlags(&S.k1_done, hipEventDisableTiming));
             LPF_HIP(c, hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
+            LPF_HIP(c, hipEventCreateWithFlags(&S.mask_done, hipEventDisableTiming));
         }
     }
     c->pipelined = on != 0;
@@ -442,7 +463,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!c) return LPF_ERR_ARG;
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
-    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr; }   // label images are W x H
+    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; }   // label images are W x H
     memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
     memcpy(c->K, K, sizeof c->K);
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
@@ -467,14 +488,16 @@ int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_
     if (use_device(c)) return LPF_ERR_HIP;
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called first");
     if (F < 0 || M < 0 || M > LPF_MAX_MASKS || (F > 0 && !label)) return fail(c, LPF_ERR_ARG, "set_label_image: F=%d M=%d", F, M);
-    c->mask_F = 0; c->mask_M = 0; c->label_cur = nullptr;
+    int rc;
+    if ((rc = sync_all(c))) return rc;
+    lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
+    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr;
     if (F == 0) return LPF_OK;
     const size_t bytes = (size_t)F * c->H * c->W * 4;
-    int rc;
-    if ((rc = reserve(c, c->label_a, bytes))) return rc;
-    LPF_HIP(c, hipMemcpyAsync(c->label_a.p, label, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));
-    c->label_cur = (uint32_t *)c->label_a.p;
+    if ((rc = reserve(c, S.label_a, bytes))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(S.label_a.p, label, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    S.label_cur = (uint32_t *)S.label_a.p;
     c->mask_F = F; c->mask_M = M;
     return LPF_OK;
 }
@@ -483,9 +506,11 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
 {
     if (!c || !out) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (!c->label_cur) return fail(c, LPF_ERR_STATE, "no masks set");
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
+    if (!S.label_cur || !c->mask_F) return fail(c, LPF_ERR_STATE, "no masks set");
     const size_t bytes = (size_t)c->mask_F * c->H * c->W * 4;
-    LPF_HIP(c, hipMemcpyAsync(out, c->label_cur, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipMemcpyAsync(out, S.label_cur, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));
     return LPF_OK;
 }
@@ -590,7 +615,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
-    P.label_img = (M > 0) ? c->label_cur : nullptr;
+    P.label_img = (M > 0) ? S.label_cur : nullptr;
+    if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "masks were set for another scratch set (toggle pipelining only with masks re-set)");
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
@@ -653,6 +679,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         c->h_frames_dev = c->h_frames;
     }
     if (pipe && S.tail_pending) LPF_HIP(c, hipStreamWaitEvent(c->stream, S.tail_done, 0));   // this set's previous tail
+    if (pipe && S.mask_pending) { LPF_HIP(c, hipStreamWaitEvent(c->stream, S.mask_done, 0)); S.mask_pending = false; }
     if (nseg_total > 0) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->profiling && c->ev_used < (1u << 16)) {
@@ -677,6 +704,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     }
     if (pipe) {                                            // hand over to the second stream
         LPF_HIP(c, hipEventRecord(S.k1_done, c->stream));
+        S.k1_recorded = true;
         LPF_HIP(c, hipStreamWaitEvent(tail_stream, S.k1_done, 0));
     }
     {
