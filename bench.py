@@ -95,8 +95,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (one context each) the steps alternate over; 2 overlaps the short kernels of one "
                          "step with the streaming kernel of the next (higher points/s, longer per-kernel durations)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run a step's tail kernels on the same stream instead of overlapping them with the next step")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap a step's short tail kernels (scan, lists, finalize) with the next step's streaming kernel on "
+                         "a second stream: more points/s, but the streaming kernel's own duration grows under the contention")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the second, event-bracketed pass")
@@ -158,7 +159,7 @@ def main():
     for st in streams:
         c = LpfContext(local_rank)
         c.set_stream(st.cuda_stream)
-        c.set_pipelined(not args.no_pipeline)
+        c.set_pipelined(args.pipeline)
         c.set_camera(T, K, W, H, 0.0, DMAX)
         c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
         ctxs.append(c)
@@ -245,7 +246,7 @@ def main():
                                    "masks + %d 3D boxes, V4 clip depth<30; one launch set per step produces all outputs "
                                    "(u,v,label,valid_idx,instance lists,count_mb,best box)" % (F, n, N_MASKS, N_BOXES),
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
-                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream, "tail_kernels_overlap_next_step": not args.no_pipeline,
+                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream, "tail_kernels_overlap_next_step": bool(args.pipeline),
                        "sharding": "clouds per rank, no data-path collective"},
         }
         if k1_n:

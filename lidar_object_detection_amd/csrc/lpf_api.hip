@@ -63,7 +63,8 @@ struct lpf_ctx {
     struct Scratch {
         DevBuf vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
         DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
-        uint32_t *label_cur = nullptr;
+        void *label_cur = nullptr;
+        int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
         hipEvent_t k1_done = nullptr, tail_done = nullptr, mask_done = nullptr;
         bool tail_pending = false, k1_recorded = false, mask_pending = false;
     } sc[2];
@@ -285,6 +286,53 @@ int build_candidates(lpf_ctx *c, int F)
     return LPF_OK;
 }
 
+// masks -> label image with element type LT, on stream ms, into S.label_a (S.label_b = erosion ping-pong)
+template <typename T, typename LT>
+int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks, int F, int M, int mode, int erode_iters, void **result)
+{
+    const size_t hw = (size_t)c->H * c->W;
+    dim3 grid((c->W + LPF_TW - 1) / LPF_TW, (c->H + LPF_TH - 1) / LPF_TH, F);
+    LT *cur = (LT *)S.label_a.p;
+    int rc;
+    if (M == 0) {
+        LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * sizeof(LT), ms));
+    } else {
+        int left = erode_iters;
+        if (hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
+            // streaming pack, 16 pixels per lane; erosion (if any) then runs on the packed image
+            const long long total16 = (long long)F * (long long)(hw / 16);
+            const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+            if (mode == 0)
+                hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+            else if (mode == 1)
+                hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+            else
+                hipLaunchKernelGGL((lpf_pack16<T, 2, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+        } else {
+            const int fuse = erode_iters > 0 ? 1 : 0;
+            left -= fuse;
+            if (mode == 0)
+                hipLaunchKernelGGL((lpf_pack_erode<T, 0, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+            else if (mode == 1)
+                hipLaunchKernelGGL((lpf_pack_erode<T, 1, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+            else
+                hipLaunchKernelGGL((lpf_pack_erode<T, 2, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+        }
+        LPF_HIP(c, hipGetLastError());
+        if (left > 0) {
+            if ((rc = reserve(c, S.label_b, (size_t)F * hw * 4))) return rc;
+            LT *other = (LT *)S.label_b.p;
+            for (int it = 0; it < left; ++it) {
+                hipLaunchKernelGGL((lpf_erode_packed<LT>), grid, dim3(LPF_BLOCK), 0, ms, cur, other, c->H, c->W);
+                LPF_HIP(c, hipGetLastError());
+                LT *t = cur; cur = other; other = t;
+            }
+        }
+    }
+    *result = cur;
+    return LPF_OK;
+}
+
 template <typename T>
 int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode_iters, int on_device)
 {
@@ -318,43 +366,13 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         LPF_HIP(c, hipMemcpyAsync(c->mask_stage.p, masks, bytes, hipMemcpyHostToDevice, c->stream));
         d_masks = (const T *)c->mask_stage.p;
     }
-    dim3 grid((c->W + LPF_TW - 1) / LPF_TW, (c->H + LPF_TH - 1) / LPF_TH, F);
-    uint32_t *cur = (uint32_t *)S.label_a.p;
-    if (M == 0) {
-        LPF_HIP(c, hipMemsetAsync(cur, 0, (size_t)F * hw * 4, ms));
-    } else {
-        int left = erode_iters;
-        if (hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
-            // streaming pack, 16 pixels per lane; erosion (if any) then runs on the packed image
-            const long long total16 = (long long)F * (long long)(hw / 16);
-            const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
-            if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack16<T, 0>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
-            else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack16<T, 1>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
-            else
-                hipLaunchKernelGGL((lpf_pack16<T, 2>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
-        } else {
-            const int fuse = erode_iters > 0 ? 1 : 0;
-            left -= fuse;
-            if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 0>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
-            else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 1>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
-            else
-                hipLaunchKernelGGL((lpf_pack_erode<T, 2>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
-        }
-        LPF_HIP(c, hipGetLastError());
-        if (left > 0) {
-            if ((rc = reserve(c, S.label_b, (size_t)F * hw * 4))) return rc;
-            uint32_t *other = (uint32_t *)S.label_b.p;
-            for (int it = 0; it < left; ++it) {
-                hipLaunchKernelGGL(lpf_erode_packed, grid, dim3(LPF_BLOCK), 0, ms, cur, other, c->H, c->W);
-                LPF_HIP(c, hipGetLastError());
-                uint32_t *t = cur; cur = other; other = t;
-            }
-        }
-    }
+    const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
+    void *cur = nullptr;
+    if (lb == 1) rc = pack_typed<T, uint8_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
+    else if (lb == 2) rc = pack_typed<T, uint16_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
+    else rc = pack_typed<T, uint32_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
+    if (rc) return rc;
+    S.label_bytes = lb;
     if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
     if (pipe) { LPF_HIP(c, hipEventRecord(S.mask_done, ms)); S.mask_pending = true; }
     S.label_cur = cur;
@@ -497,7 +515,8 @@ int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_
     if ((rc = reserve(c, S.label_a, bytes))) return rc;
     LPF_HIP(c, hipMemcpyAsync(S.label_a.p, label, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));
-    S.label_cur = (uint32_t *)S.label_a.p;
+    S.label_cur = S.label_a.p;
+    S.label_bytes = 4;
     c->mask_F = F; c->mask_M = M;
     return LPF_OK;
 }
@@ -509,8 +528,20 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
     if (!S.label_cur || !c->mask_F) return fail(c, LPF_ERR_STATE, "no masks set");
-    const size_t bytes = (size_t)c->mask_F * c->H * c->W * 4;
-    LPF_HIP(c, hipMemcpyAsync(out, S.label_cur, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    const size_t npix = (size_t)c->mask_F * c->H * c->W;
+    if (S.label_bytes == 4) {
+        LPF_HIP(c, hipMemcpyAsync(out, S.label_cur, npix * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        return LPF_OK;
+    }
+    // narrow label images (M <= 16) are widened on the host: this entry point exists for tests
+    std::vector<uint8_t> raw(npix * (size_t)S.label_bytes);
+    LPF_HIP(c, hipMemcpyAsync(raw.data(), S.label_cur, raw.size(), hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> wide(npix);
+    for (size_t i = 0; i < npix; ++i)
+        wide[i] = S.label_bytes == 1 ? (uint32_t)raw[i] : (uint32_t)reinterpret_cast<const uint16_t *>(raw.data())[i];
+    LPF_HIP(c, hipMemcpyAsync(out, wide.data(), npix * 4, on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));
     return LPF_OK;
 }
@@ -695,10 +726,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         }
         // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
         P.tile_pts = (Ntot <= (4ll << 20)) ? 512 : 1024;
-        if (Ntot <= (4ll << 20))
-            hipLaunchKernelGGL((lpf_k1_project_t<2, LPF_K1_FLAGS>), dim3(nseg_total * (unsigned)(seg_pts / 512)), dim3(LPF_BLOCK), 0, c->stream, P);
-        else
-            hipLaunchKernelGGL((lpf_k1_project_t<4, LPF_K1_FLAGS>), dim3(nseg_total * (unsigned)(seg_pts / 1024)), dim3(LPF_BLOCK), 0, c->stream, P);
+        const bool small = Ntot <= (4ll << 20);
+        const dim3 g1(nseg_total * (unsigned)(seg_pts / (small ? 512 : 1024)));
+        const int lb = (M > 0) ? S.label_bytes : 4;
+#define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
+        if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
+        else       { if (lb == 1) LPF_K1_LAUNCH(4, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(4, uint16_t); else LPF_K1_LAUNCH(4, uint32_t); }
+#undef LPF_K1_LAUNCH
         LPF_HIP(c, hipGetLastError());
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
     }

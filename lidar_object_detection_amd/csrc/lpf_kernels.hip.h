@@ -52,7 +52,7 @@ struct LpfParams {
     const LpfFrame *frames;      // [F]
     const LpfFrame *segs;        // [nseg_total] the owning frame's record per segment (pad = frame id)
     const float4 *pts;
-    const uint32_t *label_img;   // [F][H][W] or null
+    const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
     const double *boxp;          // [Btot][16] exact box parameters
     const float *boxq;           // [Btot][8]  conservative float AABB {lo xyz, hi xyz}
     const unsigned long long *cand;   // per frame [cells][cand_words]: boxes whose accepted region can project into the cell
@@ -167,7 +167,7 @@ __device__ __forceinline__ void lpf_project_point(const LpfParams &P, float fx, 
 #define LPF_F_LAB_NOBAL 64u
 #define LPF_F_LAB_NOTAB 128u
 
-template <int ROWS, unsigned FL>
+template <int ROWS, unsigned FL, typename LT = uint32_t>   // LT: label-image element (uint8 for M <= 8, uint16 for M <= 16)
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
 {
     // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
     const int c = seg_start + (lb - sid * tiles_per_seg) * TILE;       // first point of the tile
     if (c >= seg_end) return;                                            // padding tile of a short segment
     const float4 *__restrict__ pts = P.pts + fr.pt_off;
-    const uint32_t *__restrict__ limg =
-        (P.label_img && P.M > 0) ? P.label_img + (size_t)f * (size_t)P.W * (size_t)P.H : nullptr;
+    const LT *__restrict__ limg =
+        (P.label_img && P.M > 0) ? static_cast<const LT *>(P.label_img) + (size_t)f * (size_t)P.W * (size_t)P.H : nullptr;
     const int rows_per_seg = P.seg_pts >> 6;
     const double Wd = (double)P.W, Hd = (double)P.H;
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
             // K4: label gather (2.1 MB image, L2 resident); consumed after the loop
             lab[r] = 0;
             if (!(FL & LPF_F_LAB_NOGATHER)) {
-                if (ok && limg) lab[r] = limg[(int)rv * P.W + (int)ru];
+                if (ok && limg) lab[r] = (uint32_t)limg[(int)rv * P.W + (int)ru];
             }
             if (live && !(FL & LPF_F_LAB_NOSTORE)) {
                 const long long g = fr.pt_off + idx;
@@ -788,8 +788,8 @@ __device__ __forceinline__ bool lpf_member(T v)
 // Streaming pack, 16 pixels per lane: uint8 masks are read 16 bytes per lane per mask
 // (float masks 4 x 16 bytes), the packed labels leave as four 16-byte stores.
 // Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).
-template <typename T, int MODE>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, uint32_t *__restrict__ label,
+template <typename T, int MODE, typename LT>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, LT *__restrict__ label,
                                                         int M, long long hw, long long total16)
 {
     const long long g = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;    // group of 16 pixels, over all frames
@@ -837,9 +837,24 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ ma
             }
         }
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(label + (size_t)f * hw + o);
+    LT *dst = label + (size_t)f * hw + o;                   // 16 pixels: 16 / 32 / 64 contiguous bytes per lane
+    if (sizeof(LT) == 1) {
+        uint4 v;
+        v.x = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
+        v.y = bits[4] | (bits[5] << 8) | (bits[6] << 16) | (bits[7] << 24);
+        v.z = bits[8] | (bits[9] << 8) | (bits[10] << 16) | (bits[11] << 24);
+        v.w = bits[12] | (bits[13] << 8) | (bits[14] << 16) | (bits[15] << 24);
+        *reinterpret_cast<uint4 *>(dst) = v;
+    } else if (sizeof(LT) == 2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dst[k] = make_uint4(bits[4 * k], bits[4 * k + 1], bits[4 * k + 2], bits[4 * k + 3]);
+        for (int k = 0; k < 2; ++k)
+            reinterpret_cast<uint4 *>(dst)[k] = make_uint4(bits[8 * k] | (bits[8 * k + 1] << 16), bits[8 * k + 2] | (bits[8 * k + 3] << 16),
+                                                            bits[8 * k + 4] | (bits[8 * k + 5] << 16), bits[8 * k + 6] | (bits[8 * k + 7] << 16));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            reinterpret_cast<uint4 *>(dst)[k] = make_uint4(bits[4 * k], bits[4 * k + 1], bits[4 * k + 2], bits[4 * k + 3]);
+    }
 }
 
 // General-shape pack with optional fused first erosion: 64x16 output tile per block,
@@ -848,8 +863,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ ma
 #define LPF_TW 64
 #define LPF_TH 16
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict__ masks, uint32_t *__restrict__ label,
+template <typename T, int MODE, typename LT>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict__ masks, LT *__restrict__ label,
                                                             int M, int H, int W, int erode)
 {
     __shared__ uint32_t s_tile[LPF_TH + 2][LPF_TW + 2 + 1];
@@ -876,13 +891,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict_
         if (y < H && x < W) {
             uint32_t v = s_tile[ty + 1][tx + 1];
             if (erode) v &= s_tile[ty][tx + 1] & s_tile[ty + 2][tx + 1] & s_tile[ty + 1][tx] & s_tile[ty + 1][tx + 2];
-            label[(size_t)f * hw + (size_t)y * W + x] = v;
+            label[(size_t)f * hw + (size_t)y * W + x] = (LT)v;
         }
     }
 }
 
 // erosion iterations on the packed image (all 32 masks per AND), LDS-staged tile
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_erode_packed(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+template <typename LT>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_erode_packed(const LT *__restrict__ in, LT *__restrict__ out,
                                                               int H, int W)
 {
     __shared__ uint32_t s_tile[LPF_TH + 2][LPF_TW + 2 + 1];
@@ -892,14 +908,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_erode_packed(const uint32_t *__
     for (int p = threadIdx.x; p < (LPF_TH + 2) * (LPF_TW + 2); p += LPF_BLOCK) {
         const int ty = p / (LPF_TW + 2), tx = p - ty * (LPF_TW + 2);
         const int y = y0 + ty - 1, x = x0 + tx - 1;
-        s_tile[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? in[(size_t)f * hw + (size_t)y * W + x] : 0xFFFFFFFFu;
+        s_tile[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? (uint32_t)in[(size_t)f * hw + (size_t)y * W + x] : 0xFFFFFFFFu;
     }
     __syncthreads();
     const int tx = threadIdx.x & (LPF_TW - 1);
     for (int ty = threadIdx.x >> 6; ty < LPF_TH; ty += LPF_BLOCK / LPF_TW) {
         const int y = y0 + ty, x = x0 + tx;
         if (y < H && x < W)
-            out[(size_t)f * hw + (size_t)y * W + x] = s_tile[ty + 1][tx + 1] & s_tile[ty][tx + 1] & s_tile[ty + 2][tx + 1] &
-                                                       s_tile[ty + 1][tx] & s_tile[ty + 1][tx + 2];
+            out[(size_t)f * hw + (size_t)y * W + x] = (LT)(s_tile[ty + 1][tx + 1] & s_tile[ty][tx + 1] & s_tile[ty + 2][tx + 1] &
+                                                            s_tile[ty + 1][tx] & s_tile[ty + 1][tx + 2]);
     }
 }
