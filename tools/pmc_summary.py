@@ -27,8 +27,10 @@ def per_kernel(path):
 
 def main():
     root, prefix, out = sys.argv[1:4]
-    f = per_kernel(glob.glob("%s/%s_FETCH_SIZE/*/*_counter_collection.csv" % (root, prefix))[0])
-    w = per_kernel(glob.glob("%s/%s_WRITE_SIZE/*/*_counter_collection.csv" % (root, prefix))[0])
+    import os
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)       # a directory may hold earlier passes too
+    f = per_kernel(newest("%s/%s_FETCH_SIZE/*/*_counter_collection.csv" % (root, prefix)))
+    w = per_kernel(newest("%s/%s_WRITE_SIZE/*/*_counter_collection.csv" % (root, prefix)))
     res = {}
     for k in sorted(set(f) | set(w)):
         if "lpf" not in k and "ref_" not in k:
