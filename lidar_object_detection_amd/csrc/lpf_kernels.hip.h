@@ -107,22 +107,20 @@ __device__ __forceinline__ int32_t lpf_sat_i32(double r)
     return (r != r) ? INT32_MIN : v;
 }
 
-// biased exponent in [723, 1323]  <=>  2^-300 <= |x| < 2^301 (finite, normal, non-zero)
-__device__ __forceinline__ bool lpf_mid_range(double x)
-{
-    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
-    return (e - 723u) <= 600u;
-}
+// biased exponent field of a double (0 for zero/subnormal, 2047 for inf/nan)
+__device__ __forceinline__ unsigned lpf_expo(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
 
 // (qx/ad, qy/ad), both correctly rounded.  The compiler's IEEE f64 division is
 // div_scale -> rcp -> two Newton steps -> mul -> residual fma -> div_fmas -> div_fixup;
-// when all operands are mid-range the scale/fixup steps are identities, so the same
-// arithmetic with ONE shared reciprocal gives the same bits for both quotients at about
-// half the instructions.  Anything else (zeros, subnormals, inf, nan, huge ratios) takes
-// the plain '/' operator.
+// when all operands are mid-range (2^-300 <= |x| < 2^301: biased exponent in [723, 1323]) the
+// scale/fixup steps are identities, so the same arithmetic with ONE shared reciprocal gives the
+// same bits for both quotients at about half the instructions.  Anything else (zeros,
+// subnormals, inf, nan, huge ratios) takes the plain '/' operator.
 __device__ __forceinline__ void lpf_div2(double qx, double qy, double ad, double &uf, double &vf)
 {
-    if (lpf_mid_range(ad) && lpf_mid_range(qx) && lpf_mid_range(qy)) {
+    const unsigned ea = lpf_expo(ad), ex = lpf_expo(qx), ey = lpf_expo(qy);
+    const unsigned lo = min(ea, min(ex, ey)), hi = max(ea, max(ex, ey));       // v_min3_u32 / v_max3_u32
+    if (lo >= 723u && hi <= 1323u) {
         double r = __builtin_amdgcn_rcp(ad);
         double e = fma(-ad, r, 1.0); r = fma(r, e, r);
         e = fma(-ad, r, 1.0);        r = fma(r, e, r);
@@ -189,8 +187,6 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
     const LT *__restrict__ limg =
         (P.label_img && P.M > 0) ? static_cast<const LT *>(P.label_img) + (size_t)f * (size_t)P.W * (size_t)P.H : nullptr;
     const int rows_per_seg = P.seg_pts >> 6;
-    const double Wd = (double)P.W, Hd = (double)P.H;
-
     if (tid < LPF_TAB_ROWS) s_cnt[tid] = 0;
     __syncthreads();
     unsigned nvalid_w = 0, nmask_w = 0;
@@ -226,24 +222,26 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
                 lpf_project_point(P, p[r].x, p[r].y, p[r].z, uf, vf, d);
                 ru = rint(uf); rv = rint(vf);                   // np.round: half to even
             }
-            // K3: clip
-            const bool ok = live && (ru >= 0.0) && (ru < Wd) && (rv >= 0.0) && (rv < Hd) &&
+            // K3: clip.  ru, rv are integral: 0 <= ru < W  <=>  (unsigned)sat_i32(ru) < W  (saturation and
+            // NaN -> INT32_MIN both land outside), so the image test runs on the integers (u, v)
+            const int ui = lpf_sat_i32(ru), vi = lpf_sat_i32(rv);
+            const bool ok = live && ((unsigned)ui < (unsigned)P.W) && ((unsigned)vi < (unsigned)P.H) &&
                             (d > P.dmin) && (d < P.dmax);
             valid[r] = ok;
             // K4: label gather (2.1 MB image, L2 resident); consumed after the loop
             lab[r] = 0;
             if (!(FL & LPF_F_LAB_NOGATHER)) {
-                if (ok && limg) lab[r] = (uint32_t)limg[(int)rv * P.W + (int)ru];
+                if (ok && limg) lab[r] = (uint32_t)limg[vi * P.W + ui];
             }
             if (live && !(FL & LPF_F_LAB_NOSTORE)) {
                 const long long g = fr.pt_off + idx;
                 if (P.uv) {
                     if (FL & LPF_F_NTSTORE) {
                         typedef int i2v __attribute__((ext_vector_type(2)));
-                        i2v t; t.x = lpf_sat_i32(ru); t.y = lpf_sat_i32(rv);
+                        i2v t; t.x = ui; t.y = vi;
                         __builtin_nontemporal_store(t, reinterpret_cast<i2v *>(P.uv + g));
                     } else {
-                        P.uv[g] = make_int2(lpf_sat_i32(ru), lpf_sat_i32(rv));
+                        P.uv[g] = make_int2(ui, vi);
                     }
                 }
                 if (P.depth) P.depth[g] = d;
