@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap a step's short tail kernels (scan, lists, finalize) with the next step's streaming kernel on "
                          "a second stream: more points/s, but the streaming kernel's own duration grows under the contention")
+    ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path without RCCL")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the second, event-bracketed pass")
@@ -115,11 +117,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
@@ -183,12 +191,12 @@ def main():
             torch.cuda.synchronize(dev)                             # all streams: the last step may be on any of them
             sm = np.frombuffer(outs[(k - 1) % nbuf]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
             agg = torch.tensor([int(sm["n_valid"].sum()), int(sm["n_labelled"].sum()), int(sm["inst_count"].sum()), F],
-                               dtype=torch.int64, device=dev)
+                               dtype=torch.int64, device=cdev)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         barrier()
         el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
