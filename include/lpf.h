@@ -138,6 +138,18 @@ int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int 
 int lpf_points_in_boxes(lpf_ctx *ctx, const float *pts, int64_t k, int stride, const double *corners_velo,
                         int B, int oriented, uint8_t *inside, int on_device);
 
+/* ---- box preparation on the GPU --------------------------------------------------------------
+ * For nbox annotated boxes given by their 8 corners in the cam-0 frame (f64 [nbox][8][3], the
+ * 'corners_cam0' of BBoxes_<frame>.json):
+ *   visible[b]      = 1 if filter_visible_bboxes keeps the box (V3:121-140; needs lpf_set_camera's K, W, H)
+ *   corners_velo    = transform_bboxes_to_velodyne's output (V3:41-52), f64 [nbox][8][3];
+ *                     T_cam_to_velo = inv(TrVeloToCam), row-major 4x4
+ *   bbox2d[b][4]    = {min u, min v, max u, max v} of the projected corners with depth > 0 and
+ *   front[b]        = how many corners those are (V4:157-168; 0 -> the box is skipped by the IoU match)
+ * Any output may be NULL.  Host pointers. */
+int lpf_prepare_boxes(lpf_ctx *ctx, const double *corners_cam0, int nbox, const double T_cam_to_velo[16],
+                      uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front);
+
 /* ---- hipGraph capture of a launch set ------------------------------------------------------
  * lpf_graph_begin puts the context's stream into capture mode; every device-mode lpf_set_masks_* /
  * lpf_run* call issued until lpf_graph_end is recorded instead of executed (pointers and sizes are

@@ -77,6 +77,7 @@ def load():
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
+    lib.lpf_prepare_boxes.argtypes = [_P, _P, ctypes.c_int, _P, _P, _P, _P, _P]
     lib.lpf_graph_begin.argtypes = [_P]
     lib.lpf_graph_end.argtypes = [_P, ctypes.POINTER(_P)]
     lib.lpf_graph_launch.argtypes = [_P, _P]
@@ -91,7 +92,7 @@ def load():
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_profile_enable", "lpf_profile_read",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_profile_enable", "lpf_profile_read",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy")
 
 
@@ -269,6 +270,20 @@ class LpfContext:
             self._check(self._lib.lpf_points_in_boxes(self._h, p.ctypes.data, k, p.shape[1], c.ctypes.data, B,
                                                       int(bool(oriented)), out.ctypes.data, 0))
         return out.astype(bool)
+
+    def prepare_boxes(self, corners_cam0, T_cam_to_velo):
+        """(visible bool[B], corners_velo f64[B,8,3], bbox2d f64[B,4], front int32[B]) of B annotated boxes
+        given by their cam-0 corners: filter_visible_bboxes + transform_bboxes_to_velodyne + V4's projected
+        2D box, computed on the GPU with the reference's arithmetic (needs set_camera first)."""
+        c = np.ascontiguousarray(corners_cam0, dtype=np.float64).reshape(-1, 8, 3)
+        T = np.ascontiguousarray(T_cam_to_velo, dtype=np.float64).reshape(16)
+        B = c.shape[0]
+        vis, cv = np.zeros(B, np.uint8), np.zeros((B, 8, 3), np.float64)
+        bb, fr = np.zeros((B, 4), np.float64), np.zeros(B, np.int32)
+        if B:
+            self._check(self._lib.lpf_prepare_boxes(self._h, c.ctypes.data, B, T.ctypes.data, vis.ctypes.data, cv.ctypes.data,
+                                                    bb.ctypes.data, fr.ctypes.data))
+        return vis.astype(bool), cv, bb, fr
 
     # -- the hot path, host arrays ------------------------------------------------------
     def run(self, points, **kw):

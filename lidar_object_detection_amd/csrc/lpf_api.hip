@@ -73,7 +73,7 @@ struct lpf_ctx {
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
-    DevBuf pib_box, pib_pts, pib_out;
+    DevBuf pib_box, pib_pts, pib_out, boxprep;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
     std::vector<LpfFrame> h_segs;
@@ -424,7 +424,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -829,6 +829,35 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
     LPF_HIP(c, hipGetLastError());
     if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));           // bp is a local
+    return LPF_OK;
+}
+
+int lpf_prepare_boxes(lpf_ctx *c, const double *corners_cam0, int nbox, const double Tcv[16], uint8_t *visible, double *corners_velo,
+                      double *bbox2d, int32_t *front)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera has not been called");
+    if (nbox < 0 || (nbox > 0 && (!corners_cam0 || !Tcv))) return fail(c, LPF_ERR_ARG, "prepare_boxes: nbox=%d", nbox);
+    if (nbox == 0) return LPF_OK;
+    const size_t nb = (size_t)nbox;
+    const size_t o_in = 0, o_T = o_in + nb * 192, o_K = o_T + 128, o_cv = o_K + 72 + 56 /*pad to 256*/, o_bb = o_cv + nb * 192,
+                 o_fr = o_bb + nb * 32, o_vis = o_fr + nb * 4, total = o_vis + nb;
+    int rc;
+    if ((rc = reserve(c, c->boxprep, total))) return rc;
+    char *base = (char *)c->boxprep.p;
+    LPF_HIP(c, hipMemcpyAsync(base + o_in, corners_cam0, nb * 192, hipMemcpyHostToDevice, c->stream));
+    LPF_HIP(c, hipMemcpyAsync(base + o_T, Tcv, 128, hipMemcpyHostToDevice, c->stream));
+    LPF_HIP(c, hipMemcpyAsync(base + o_K, c->K, 72, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(lpf_box_prep_kernel, dim3((unsigned)((nb * 8 + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,
+                       (const double *)(base + o_in), nbox, (const double *)(base + o_T), (const double *)(base + o_K), c->W, c->H,
+                       (uint8_t *)(base + o_vis), (double *)(base + o_cv), (double *)(base + o_bb), (int *)(base + o_fr));
+    LPF_HIP(c, hipGetLastError());
+    if (visible) LPF_HIP(c, hipMemcpyAsync(visible, base + o_vis, nb, hipMemcpyDeviceToHost, c->stream));
+    if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, base + o_cv, nb * 192, hipMemcpyDeviceToHost, c->stream));
+    if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, base + o_bb, nb * 32, hipMemcpyDeviceToHost, c->stream));
+    if (front) LPF_HIP(c, hipMemcpyAsync(front, base + o_fr, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
     return LPF_OK;
 }
 

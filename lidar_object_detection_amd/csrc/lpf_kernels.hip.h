@@ -765,6 +765,60 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_points_in_boxes_kernel(const fl
 }
 
 // ------------------------------------------------------------------------------------
+// Box preparation: for every annotated box, from its 8 corners in the cam-0 frame,
+//   visible[b]      filter_visible_bboxes (V3:121-140): >= 2 corners with depth > 0.1 inside the image,
+//                   corners projected WITHOUT R_rect (reference quirk, kept)
+//   corners_velo[b] transform_bboxes_to_velodyne (V3:41-52): (inv(TrVeloToCam) . [c 1])[:3]
+//   bbox2d[b]       V4:157-168: min/max of the integer (u, v) over the corners with depth > 0
+//                   ({umin, vmin, umax, vmax} as doubles; front[b] = number of such corners)
+// One thread per corner, 8 lanes per box; float64 with NumPy's dgemm order (k-ordered fma chains).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const double *__restrict__ corners_cam, int nbox,
+                                                                 const double *__restrict__ Tcv /*[16] cam->velo*/,
+                                                                 const double *__restrict__ K /*[9]*/, int W, int H,
+                                                                 uint8_t *__restrict__ visible, double *__restrict__ corners_velo,
+                                                                 double *__restrict__ bbox2d, int *__restrict__ front)
+{
+    const int t = blockIdx.x * LPF_BLOCK + threadIdx.x;
+    const int b = t >> 3, k = t & 7;
+    const bool live = b < nbox;
+    double x = 0, y = 0, z = 0;
+    if (live) { const double *c = corners_cam + ((size_t)b * 8 + k) * 3; x = c[0]; y = c[1]; z = c[2]; }
+    // cam2image on the raw cam-0 corners
+    double qx = K[0] * x; qx = fma(K[1], y, qx); qx = fma(K[2], z, qx);
+    double qy = K[3] * x; qy = fma(K[4], y, qy); qy = fma(K[5], z, qy);
+    double d  = K[6] * x; d  = fma(K[7], y, d);  d  = fma(K[8], z, d);
+    if (d == 0.0) d = -1e-6;
+    const double ad = fabs(d);
+    const double ru = rint(qx / ad), rv = rint(qy / ad);
+    const bool in_img = (ru >= 0.0) && (ru < (double)W) && (rv >= 0.0) && (rv < (double)H);
+    const bool vis = live && (d > 0.1) && in_img;
+    const bool fr = live && (d > 0.0);
+    // 8-lane group reductions (lanes of one box are contiguous and 8-aligned inside the wave)
+    const unsigned long long grp = 0xFFull << (lpf_lane() & 56);
+    const int nvis = __popcll(__ballot(vis) & grp), nfront = __popcll(__ballot(fr) & grp);
+    double umin = fr ? ru : 1e300, umax = fr ? ru : -1e300, vmin = fr ? rv : 1e300, vmax = fr ? rv : -1e300;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        umin = fmin(umin, __shfl_xor(umin, o)); umax = fmax(umax, __shfl_xor(umax, o));
+        vmin = fmin(vmin, __shfl_xor(vmin, o)); vmax = fmax(vmax, __shfl_xor(vmax, o));
+    }
+    if (live) {
+        double *o = corners_velo + ((size_t)b * 8 + k) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a = Tcv[4 * i] * x; a = fma(Tcv[4 * i + 1], y, a); a = fma(Tcv[4 * i + 2], z, a); a = fma(Tcv[4 * i + 3], 1.0, a);
+            o[i] = a;
+        }
+        if (k == 0) {
+            visible[b] = (uint8_t)(nvis >= 2);
+            front[b] = nfront;
+            bbox2d[4 * b] = umin; bbox2d[4 * b + 1] = vmin; bbox2d[4 * b + 2] = umax; bbox2d[4 * b + 3] = vmax;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K8: masks -> label image.
 //   MODE 0: uint8, nonzero.  MODE 1: float, astype(uint8) != 0.  MODE 2: float, (x*255) -> u8 == 255.
 // ------------------------------------------------------------------------------------

@@ -84,6 +84,29 @@ def transform_bboxes_to_velodyne(bboxes_3d, TrVeloToCam):
     return bboxes_3d
 
 
+def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0):
+    """filter_visible_bboxes + transform_bboxes_to_velodyne (+ V4's projected 2D box) in one GPU call
+    (SURVEY 8f-1): returns the visible boxes, in order, each a copy of the input dict with
+    'corners_velo' (list, as the reference stores it) and '_bbox2d' / '_front' for the IoU match.
+    The camera of the context is set to (camera.K, width, height)."""
+    have = [b for b in bboxes_3d_raw if "corners_cam0" in b]
+    if not have:
+        return []
+    ctx = get_context(device)
+    ctx.set_camera(np.eye(4), camera.K, camera.width, camera.height, 0.0, 1.0)
+    corners = np.array([b["corners_cam0"] for b in have], np.float64).reshape(-1, 8, 3)
+    vis, cv, bb, fr = ctx.prepare_boxes(corners, np.linalg.inv(TrVeloToCam))
+    out = []
+    for i, b in enumerate(have):
+        if vis[i]:
+            d = dict(b)
+            d["corners_velo"] = cv[i].tolist()
+            d["_bbox2d"] = bb[i].tolist() if fr[i] > 0 else None
+            d["_front"] = int(fr[i])
+            out.append(d)
+    return out
+
+
 def _corners_velo(bboxes_3d):
     """f64 [B,8,3] of the boxes that carry 'corners_velo' + their positions in the list."""
     pos = [i for i, b in enumerate(bboxes_3d) if "corners_velo" in b]
@@ -289,6 +312,9 @@ def match_detections_to_bboxes(boxes_2d, bboxes_3d, colors, camera, min_iou=0.25
         if "corners_cam0" not in bbox:
             proj.append(None)
             continue
+        if "_bbox2d" in bbox:                                 # projected on the GPU by prepare_boxes
+            proj.append(bbox["_bbox2d"])
+            continue
         u, v, depth = camera.cam2image(np.array(bbox["corners_cam0"]).T)
         front = depth > 0
         proj.append([np.min(u[front]), np.min(v[front]), np.max(u[front]), np.max(v[front])] if front.sum() else None)
@@ -487,7 +513,7 @@ def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, ca
         raw = kitti360.load_bounding_boxes(os.path.join(bbox_dir, f"BBoxes_{frame}.json"))
         if not raw:
             continue
-        boxes = transform_bboxes_to_velodyne(filter_visible_bboxes(raw, camera), velo_to_cam)
+        boxes = prepare_boxes(raw, camera, velo_to_cam)
         image_path = os.path.join(kitti360_path, "data_2d_raw", sequence, f"image_{cam_id:02d}",
                                   "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
         if not os.path.isfile(image_path):

@@ -163,3 +163,28 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
     assert got == expect and len(expect) > 5
     text = out.getvalue()
     assert "Found 5 frames to process" in text and "No bounding boxes found" in text and "OVERALL ANALYSIS" in text
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+def test_prepare_boxes_on_gpu(rec, calib):
+    """visibility filter + cam->velo transform + projected 2D boxes on the GPU, bit-exact against
+    the reference's filter_visible_bboxes / transform_bboxes_to_velodyne / match_detections_to_bboxes outputs."""
+    g = load_golden(rec["frame"])
+    cam = _camera(calib)
+    raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
+    vis = pipeline.prepare_boxes(raw, cam, calib["TrVeloToCam"])
+    assert [b["index"] for b in vis] == [int(g["box_index_raw"][p]) for p in g["visible_pos"]]
+    got = np.array([b["corners_velo"] for b in vis]).reshape(-1, 8, 3)
+    assert np.array_equal(got, g["corners_velo"])
+    assert all(isinstance(b["corners_velo"], list) for b in vis)
+    # the projected 2D boxes: same integers as cam2image on the host
+    for b in vis:
+        u, v, d = cam.cam2image(np.array(b["corners_cam0"]).T)
+        f = d > 0
+        assert b["_front"] == int(f.sum())
+        if f.any():
+            assert b["_bbox2d"] == [float(u[f].min()), float(v[f].min()), float(u[f].max()), float(v[f].max())]
+    for kind in ("rect5", "edge"):
+        boxes2d = g["boxes2d_" + kind]
+        pairs = pipeline.match_detections_to_bboxes(boxes2d, vis, pipeline.default_colors(len(boxes2d)), cam)
+        assert np.array_equal(np.array([p[0] for p in pairs]).reshape(-1, 8, 3), g["iou_match_corners_" + kind])
