@@ -138,6 +138,14 @@ int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int 
 int lpf_points_in_boxes(lpf_ctx *ctx, const float *pts, int64_t k, int stride, const double *corners_velo,
                         int B, int oriented, uint8_t *inside, int on_device);
 
+/* ---- last-writer depth image -------------------------------------------------------------------
+ * seg_with_pointcloud.py:160-170 fills, per mask, depthMap[v,u] = depth[idx] for idx ascending over
+ * the valid points inside the mask; the last valid point of a pixel wins whatever the mask, so one
+ * image describes all of them: depthMap_i = where(mask_i > 0.5, D, 0).  depth_img: f64 [H][W]
+ * (0 where no valid point projects), winner: int32 [H][W] index of that point or -1 (may be NULL).
+ * Uses lpf_set_camera's transform and depth window.  pts as in lpf_run; outputs follow on_device. */
+int lpf_depth_image(lpf_ctx *ctx, const float *pts, int64_t N, int on_device, double *depth_img, int32_t *winner);
+
 /* ---- box preparation on the GPU --------------------------------------------------------------
  * For nbox annotated boxes given by their 8 corners in the cam-0 frame (f64 [nbox][8][3], the
  * 'corners_cam0' of BBoxes_<frame>.json):

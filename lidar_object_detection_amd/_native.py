@@ -77,6 +77,7 @@ def load():
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
+    lib.lpf_depth_image.argtypes = [_P, _P, _I64, ctypes.c_int, _P, _P]
     lib.lpf_prepare_boxes.argtypes = [_P, _P, ctypes.c_int, _P, _P, _P, _P, _P]
     lib.lpf_graph_begin.argtypes = [_P]
     lib.lpf_graph_end.argtypes = [_P, ctypes.POINTER(_P)]
@@ -92,7 +93,7 @@ def load():
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_profile_enable", "lpf_profile_read",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy")
 
 
@@ -270,6 +271,14 @@ class LpfContext:
             self._check(self._lib.lpf_points_in_boxes(self._h, p.ctypes.data, k, p.shape[1], c.ctypes.data, B,
                                                       int(bool(oriented)), out.ctypes.data, 0))
         return out.astype(bool)
+
+    def depth_image(self, points):
+        """(D f64[H,W], winner int32[H,W]) of f32[N,4] host points: depth of the last valid point per pixel."""
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        D, win = np.empty((self.H, self.W), np.float64), np.empty((self.H, self.W), np.int32)
+        self._check(self._lib.lpf_depth_image(self._h, p.ctypes.data if len(p) else None, p.shape[0], 0,
+                                              D.ctypes.data, win.ctypes.data))
+        return D, win
 
     def prepare_boxes(self, corners_cam0, T_cam_to_velo):
         """(visible bool[B], corners_velo f64[B,8,3], bbox2d f64[B,4], front int32[B]) of B annotated boxes

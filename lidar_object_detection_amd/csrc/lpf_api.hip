@@ -73,7 +73,7 @@ struct lpf_ctx {
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
-    DevBuf pib_box, pib_pts, pib_out, boxprep;
+    DevBuf pib_box, pib_pts, pib_out, boxprep, dimg;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
     std::vector<LpfFrame> h_segs;
@@ -424,7 +424,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -829,6 +829,50 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
     LPF_HIP(c, hipGetLastError());
     if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, hipStreamSynchronize(c->stream));           // bp is a local
+    return LPF_OK;
+}
+
+int lpf_depth_image(lpf_ctx *c, const float *pts, int64_t N, int on_device, double *depth_img, int32_t *winner)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera has not been called");
+    if (N < 0 || N > 0x7ffffff0ll || (N > 0 && !pts) || !depth_img) return fail(c, LPF_ERR_ARG, "depth_image: N=%lld", (long long)N);
+    const size_t hw = (size_t)c->W * c->H;
+    int rc;
+    if ((rc = reserve(c, c->dimg, hw * 12))) return rc;                 // f64 image + u32 winners
+    double *dD = on_device ? depth_img : (double *)c->dimg.p;
+    unsigned *dW = (unsigned *)((char *)c->dimg.p + hw * 8);
+    const float *dP = pts;
+    if (!on_device && N > 0) {
+        if ((rc = reserve(c, c->st_pts, (size_t)N * 16))) return rc;
+        LPF_HIP(c, hipMemcpyAsync(c->st_pts.p, pts, (size_t)N * 16, hipMemcpyHostToDevice, c->stream));
+        dP = (const float *)c->st_pts.p;
+    }
+    LPF_HIP(c, hipMemsetAsync(dD, 0, hw * 8, c->stream));
+    LPF_HIP(c, hipMemsetAsync(dW, 0, hw * 4, c->stream));
+    if (N > 0) {
+        LpfParams P;
+        memset(&P, 0, sizeof P);
+        memcpy(P.T, c->T, sizeof P.T); memcpy(P.K, c->K, sizeof P.K);
+        P.dmin = c->dmin; P.dmax = c->dmax; P.W = c->W; P.H = c->H; P.pts = (const float4 *)dP;
+        const dim3 g((unsigned)((N + LPF_BLOCK - 1) / LPF_BLOCK));
+        hipLaunchKernelGGL((lpf_depth_image_kernel<0>), g, dim3(LPF_BLOCK), 0, c->stream, P, (int)N, dW, dD);
+        hipLaunchKernelGGL((lpf_depth_image_kernel<1>), g, dim3(LPF_BLOCK), 0, c->stream, P, (int)N, dW, dD);
+        LPF_HIP(c, hipGetLastError());
+    }
+    if (!on_device) {
+        LPF_HIP(c, hipMemcpyAsync(depth_img, dD, hw * 8, hipMemcpyDeviceToHost, c->stream));
+        if (winner) {
+            LPF_HIP(c, hipMemcpyAsync(winner, dW, hw * 4, hipMemcpyDeviceToHost, c->stream));
+            LPF_HIP(c, hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < hw; ++i) winner[i] -= 1;          // stored as index + 1, 0 = none
+            return LPF_OK;
+        }
+        LPF_HIP(c, hipStreamSynchronize(c->stream));
+    } else if (winner) {
+        return fail(c, LPF_ERR_ARG, "depth_image: the winner image is only returned to host callers");
+    }
     return LPF_OK;
 }
 

@@ -765,6 +765,29 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_points_in_boxes_kernel(const fl
 }
 
 // ------------------------------------------------------------------------------------
+// Last-writer depth image (seg_with_pointcloud.py:160-170): D[v][u] = depth of the valid
+// point with the LARGEST index projecting to (u, v); the reference's per-mask maps are where(mask, D, 0).
+// Pass 1 takes the per-pixel maximum of (index + 1) with integer atomics (deterministic), pass 2 lets
+// the winner write its depth.  Both stream the cloud once with the K1 arithmetic.
+// ------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_depth_image_kernel(const LpfParams P, int n, unsigned *__restrict__ win,
+                                                                    double *__restrict__ D)
+{
+    const int i = blockIdx.x * LPF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = P.pts[i];
+    double uf, vf, d;
+    lpf_project_point(P, p.x, p.y, p.z, uf, vf, d);
+    const int ui = lpf_sat_i32(rint(uf)), vi = lpf_sat_i32(rint(vf));
+    if (((unsigned)ui < (unsigned)P.W) && ((unsigned)vi < (unsigned)P.H) && (d > P.dmin) && (d < P.dmax)) {
+        const size_t pix = (size_t)vi * P.W + ui;
+        if (PASS == 0) atomicMax(&win[pix], (unsigned)i + 1u);
+        else if (win[pix] == (unsigned)i + 1u) D[pix] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Box preparation: for every annotated box, from its 8 corners in the cam-0 frame,
 //   visible[b]      filter_visible_bboxes (V3:121-140): >= 2 corners with depth > 0.1 inside the image,
 //                   corners projected WITHOUT R_rect (reference quirk, kept)

@@ -130,6 +130,17 @@ def project_points(points, TrVeloToRect, camera, depth_max=50.0, want_depth=True
     return r["u"].astype(np.int64), r["v"].astype(np.int64), (r["depth"] if want_depth else None), r["valid_idx"]
 
 
+def per_car_depth_maps(points, TrVeloToRect, camera, masks, depth_max=30.0, device=0):
+    """[(car_id, depthMap f64[H,W])] as seg_with_pointcloud.py:160-170 builds them (car_id = i + 1,
+    ``depthMap[v,u] = depth`` of the last valid point in mask i at that pixel, 0 elsewhere).  The
+    scatter -- a Python loop over every valid point per mask in the reference -- runs once on the
+    GPU (the winner of a pixel does not depend on the mask); the per-mask select is elementwise."""
+    ctx = get_context(device)
+    ctx.set_camera(TrVeloToRect, camera.K, camera.width, camera.height, 0.0, float(depth_max))
+    D, _ = ctx.depth_image(_f32_points(points).reshape(-1, 4))
+    return [(i + 1, np.where(np.asarray(m) > 0.5, D, 0.0)) for i, m in enumerate(masks)]
+
+
 # ---------------------------------------------------------------------------------------
 # mask lookup (V3:211-233, cvs_erosion.py:148-162)
 # ---------------------------------------------------------------------------------------

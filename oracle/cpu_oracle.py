@@ -103,6 +103,17 @@ def points_in_box(points_xyz, corners, oriented=True):
     return out.astype(bool)
 
 
+def depth_image(points, T, K, W, H, dmin, dmax):
+    """(D f64[H,W], winner int32[H,W]): last valid point per pixel (seg_with_pointcloud.py:160-170)."""
+    p = _pts4(points)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    D, win = np.empty((H, W), np.float64), np.empty((H, W), np.int32)
+    lib().orc_depth_image(_ptr(p), _I64(p.shape[0]), _ptr(T), _ptr(K), ctypes.c_int(W), ctypes.c_int(H),
+                          ctypes.c_double(dmin), ctypes.c_double(dmax), _ptr(D), _ptr(win))
+    return D, win
+
+
 def run(points, T, K, W, H, dmin, dmax, label_img=None, M=0, corners=None, oriented=True,
         want_float=True, inst_stride=None):
     """The whole per-frame path on the CPU; mirrors LpfContext.run()'s outputs."""

@@ -211,6 +211,26 @@ void orc_points_in_box(const float *pts, int64_t k, int stride, const double *co
                                        : orc_aabb_inside(pts + i * stride, corners));
 }
 
+/* ---- per-pixel last-writer depth image (seg_with_pointcloud.py:160-170) -------------------------
+ * The reference fills, per mask, depthMap[v,u] = depth[idx] for idx ascending over the valid points
+ * whose pixel is in the mask: the last valid point of a pixel wins, independent of the mask.  So one
+ * image D (and the winning point index, -1 = none) describes all masks: depthMap_i = where(mask_i, D, 0). */
+void orc_depth_image(const float *pts, int64_t N, const double *T, const double *K, int W, int H,
+                     double dmin_excl, double dmax_excl, double *D, int32_t *winner)
+{
+    for (int64_t i = 0; i < (int64_t)W * H; ++i) { D[i] = 0.0; if (winner) winner[i] = -1; }
+    for (int64_t i = 0; i < N; ++i) {
+        double a, b, d;
+        orc_project_one(pts + 4 * i, T, K, &a, &b, &d);
+        const double ru = rint(a), rv = rint(b);
+        if ((ru >= 0.0) && (ru < (double)W) && (rv >= 0.0) && (rv < (double)H) && (d > dmin_excl) && (d < dmax_excl)) {
+            const int64_t p = (int64_t)(int32_t)rv * W + (int32_t)ru;
+            D[p] = d;
+            if (winner) winner[p] = (int32_t)i;
+        }
+    }
+}
+
 /* ---- the whole per-frame path -------------------------------------------- */
 /*
  * Mirrors lpf_run (include/lpf.h).  All outputs caller-allocated, any may be NULL

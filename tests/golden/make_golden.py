@@ -251,6 +251,21 @@ def main():
                 mp = _quiet(v3.match_car_points_to_bboxes, sets, boxes3d, colors, min_points=10, use_oriented=True)
                 out["matchpairs_count_" + tag] = np.array([int(t[2]) for t in mp], np.int64)
                 out["matchpairs_corners_" + tag] = np.array([t[0] for t in mp], np.float64).reshape(-1, 8, 3)
+            if kind == "rect5" and frame in FULL_FRAMES:
+                # per-car depth maps, the literal loop of seg_with_pointcloud.py:145-170 (depth < 30)
+                valid30 = np.logical_and.reduce((u >= 0, u < camera.width, v >= 0, v < camera.height, depth > 0, depth < 30))
+                nz_idx, nz_val, nz_off = [], [], [0]
+                for i, mask in enumerate(masks):
+                    depthMap = np.zeros((camera.height, camera.width))
+                    for idx in np.where(valid30)[0]:
+                        x, y = u[idx], v[idx]
+                        if mask[y, x] > 0.5:
+                            depthMap[y, x] = depth[idx]
+                    flat = np.flatnonzero(depthMap)
+                    nz_idx.append(flat.astype(np.int64)); nz_val.append(depthMap.ravel()[flat]); nz_off.append(nz_off[-1] + len(flat))
+                out["depthmap_idx_rect5"] = np.concatenate(nz_idx)
+                out["depthmap_val_rect5"] = np.concatenate(nz_val)
+                out["depthmap_off_rect5"] = np.array(nz_off, np.int64)
             # V4 2D-IoU matching (V4:140-183)
             pairs = v4.match_detections_to_bboxes(boxes2d, boxes3d, colors, camera)
             out["iou_match_corners_" + kind] = np.array([p[0] for p in pairs], np.float64).reshape(-1, 8, 3)

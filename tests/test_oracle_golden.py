@@ -80,3 +80,20 @@ def test_frame100_is_the_survey_frame():
 def test_frame_2717_has_no_boxes():
     rec = [r for r in FRAMES if r["frame"] == 2717][0]
     assert rec.get("skipped") == "no boxes"
+
+
+def test_depth_maps_match_reference_loop(calib):
+    """seg_with_pointcloud.py:145-170 (per-car depth maps, last writer wins) through the oracle's single
+    last-writer image: depthMap_i == where(mask_i > 0.5, D, 0)."""
+    g = load_golden(100)
+    W, H = int(calib["width"]), int(calib["height"])
+    D, win = orc.depth_image(g["points"], calib["TrVeloToRect"], calib["K"][:, :3], W, H, 0.0, 30.0)
+    masks = unpack_masks(g, "rect5", H, W)
+    off = g["depthmap_off_rect5"]
+    for i, m in enumerate(masks):
+        dm = np.where(m > 0.5, D, 0.0)
+        flat = np.flatnonzero(dm)
+        assert np.array_equal(flat, g["depthmap_idx_rect5"][off[i]:off[i + 1]])
+        assert np.array_equal(dm.ravel()[flat], g["depthmap_val_rect5"][off[i]:off[i + 1]])
+    vi = g["valid_idx_d30"]
+    assert set(np.unique(win[win >= 0])) <= set(vi.tolist()) and (win >= 0).sum() == np.count_nonzero(D)
