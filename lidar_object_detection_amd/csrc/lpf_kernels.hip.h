@@ -177,7 +177,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
     const int lb = lpf_xcd_remap(blockIdx.x, P.nseg_total * tiles_per_seg);
     const int sid = lb / tiles_per_seg;
     LpfFrame fr = P.frame0;
-    if (P.F > 1) fr = P.segs[sid];                                       // one scalar load, no search
+    if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];        // wave-uniform: scalar loads, no search
     const int f = fr.pad;
     const int seg_start = (sid - fr.seg_off) * P.seg_pts;
     const int seg_end = min(seg_start + P.seg_pts, fr.N);
@@ -513,7 +513,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     if (sid >= P.nseg_total) return;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // ---- round trip 1: everything that only depends on sid -------------------------------
-    const LpfFrame fr = (P.F > 1) ? P.segs[sid] : P.frame0;
+    LpfFrame fr = P.frame0;
+    if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];       // wave-uniform: scalar loads, one branch
     const int ngroups = (2 + P.M + 3) >> 2;
     unsigned long long vb = 0, mb = 0;
     uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
