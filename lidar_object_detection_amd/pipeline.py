@@ -84,11 +84,12 @@ def transform_bboxes_to_velodyne(bboxes_3d, TrVeloToCam):
     return bboxes_3d
 
 
-def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0):
+def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0, keep_all=False):
     """filter_visible_bboxes + transform_bboxes_to_velodyne (+ V4's projected 2D box) in one GPU call
     (SURVEY 8f-1): returns the visible boxes, in order, each a copy of the input dict with
     'corners_velo' (list, as the reference stores it) and '_bbox2d' / '_front' for the IoU match.
-    The camera of the context is set to (camera.K, width, height)."""
+    The camera of the context is set to (camera.K, width, height).  ``keep_all=True`` skips the
+    visibility filter (V5 transforms every box, V5:454-461)."""
     have = [b for b in bboxes_3d_raw if "corners_cam0" in b]
     if not have:
         return []
@@ -98,7 +99,7 @@ def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0):
     vis, cv, bb, fr = ctx.prepare_boxes(corners, np.linalg.inv(TrVeloToCam))
     out = []
     for i, b in enumerate(have):
-        if vis[i]:
+        if vis[i] or keep_all:
             d = dict(b)
             d["corners_velo"] = cv[i].tolist()
             d["_bbox2d"] = bb[i].tolist() if fr[i] > 0 else None
@@ -344,6 +345,94 @@ def match_detections_to_bboxes(boxes_2d, bboxes_3d, colors, camera, min_iou=0.25
     return pairs
 
 
+def _projected_box_info(bbox, camera):
+    """V5's project_3d_bbox_to_2d (V5:215-252) for one box dict: None when no corner is in front."""
+    if "_bbox2d" in bbox:                                   # projected on the GPU by prepare_boxes
+        bb = bbox["_bbox2d"]
+    else:
+        u, v, depth = camera.cam2image(np.array(bbox["corners_cam0"]).T)
+        front = depth > 0
+        bb = [np.min(u[front]), np.min(v[front]), np.max(u[front]), np.max(v[front])] if np.any(front) else None
+    if bb is None:
+        return None
+    x0, y0, x1, y1 = bb
+    return {"bbox": [x0, y0, x1, y1], "center": [(x0 + x1) / 2, (y0 + y1) / 2], "size": [x1 - x0, y1 - y0],
+            "area": (x1 - x0) * (y1 - y0)}
+
+
+def calculate_matching_score(detection_info, bbox_3d_info, weight_iou=0.5, weight_center=0.3, weight_size=0.2):
+    """0.5 IoU + 0.3 centre proximity + 0.2 area ratio (V5:277-304)."""
+    iou = calculate_iou_2d(detection_info["bbox"], bbox_3d_info["bbox"])
+    dist = np.linalg.norm(np.array(detection_info["center"]) - np.array(bbox_3d_info["center"]))
+    center_score = max(0, 1 - dist / 1000)
+    det_area = detection_info["size"][0] * detection_info["size"][1]
+    box_area = bbox_3d_info["area"]
+    size_ratio = min(det_area, box_area) / max(det_area, box_area) if det_area > 0 and box_area > 0 else 0
+    total = weight_iou * iou + weight_center * center_score + weight_size * size_ratio
+    return total, {"iou": iou, "center_score": center_score, "size_score": size_ratio, "total_score": total}
+
+
+def improved_match_detections_to_bboxes(boxes_2d, bboxes_3d, mask_colors, camera, min_score_threshold=0.3,
+                                        min_iou_threshold=0.15):
+    """V5's score matrix + Hungarian assignment (V5:307-416): matched boxes in the detection's colour,
+    then every unmatched box with 'corners_velo' in light grey.  Host scalars (D x B), scipy's solver."""
+    from scipy.optimize import linear_sum_assignment
+    matched = []
+    if not bboxes_3d or len(boxes_2d) == 0:
+        print("[INFO] No detections or 3D bounding boxes to match")
+        return matched
+    print(f"[INFO] Matching {len(boxes_2d)} 2D detections with {len(bboxes_3d)} 3D bboxes")
+    dets = []
+    for box in boxes_2d:
+        if len(box) == 4:
+            x1, y1, x2, y2 = box
+            dets.append({"bbox": [x1, y1, x2, y2], "center": [(x1 + x2) / 2, (y1 + y2) / 2], "size": [x2 - x1, y2 - y1],
+                         "area": (x2 - x1) * (y2 - y1)})
+    infos, valid_idx = [], []
+    for j, bbox in enumerate(bboxes_3d):
+        info = _projected_box_info(bbox, camera) if "corners_cam0" in bbox else None
+        if info is not None:
+            infos.append(info)
+            valid_idx.append(j)
+    if not infos:
+        print("[WARN] No valid 3D bbox projections found")
+        return matched
+    cost = np.zeros((len(dets), len(infos)))
+    details = {}
+    for i, d in enumerate(dets):
+        for j, b in enumerate(infos):
+            score, det = calculate_matching_score(d, b)
+            cost[i, j] = 1 - score
+            details[(i, j)] = det
+    rows, cols = linear_sum_assignment(cost)
+    used = set()
+    for i, j in zip(rows, cols):
+        sc = details[(i, j)]
+        if sc["total_score"] >= min_score_threshold and sc["iou"] >= min_iou_threshold:
+            orig = valid_idx[j]
+            used.add(orig)
+            bbox = bboxes_3d[orig]
+            if "corners_velo" in bbox:
+                if i < len(mask_colors):
+                    c = mask_colors[i]
+                    color = np.array([c[2], c[1], c[0]], dtype=float) / 255.0
+                else:
+                    color = np.array([1.0, 0.0, 0.0])
+                matched.append((np.array(bbox["corners_velo"]), color))
+                print(f"[INFO] Matched detection {i} with 3D bbox {orig}")
+                print(f"        Scores - IoU: {sc['iou']:.3f}, Center: {sc['center_score']:.3f}, "
+                      f"Size: {sc['size_score']:.3f}, Total: {sc['total_score']:.3f}")
+            else:
+                print(f"[WARN] No Velodyne corners found for bbox {orig}")
+        else:
+            print(f"[INFO] Rejected match det{i}-bbox{j}: score={sc['total_score']:.3f}, IoU={sc['iou']:.3f}")
+    for i, bbox in enumerate(bboxes_3d):
+        if i not in used and "corners_velo" in bbox:
+            matched.append((np.array(bbox["corners_velo"]), [0.7, 0.7, 0.7]))
+            print(f"[INFO] Added unmatched 3D bbox {i} in default color")
+    return matched
+
+
 # ---------------------------------------------------------------------------------------
 # reporting (V3:431-468, cvs_erosion.py:232-295)
 # ---------------------------------------------------------------------------------------
@@ -506,7 +595,8 @@ def sequence_setup(kitti360_path, seq=0, cam_id=0):
     return sequence, camera, velo_to_cam, velo_to_rect, velo
 
 
-def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None):
+def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None,
+                         keep_all_boxes=False):
     """The reference's per-frame loading + skip rules (cvs_erosion.py:320-369): a frame is
     dropped when its scan, its box file, its image or its detections are missing."""
     sequence = "2013_05_28_drive_%04d_sync" % seq
@@ -524,7 +614,7 @@ def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, ca
         raw = kitti360.load_bounding_boxes(os.path.join(bbox_dir, f"BBoxes_{frame}.json"))
         if not raw:
             continue
-        boxes = prepare_boxes(raw, camera, velo_to_cam)
+        boxes = prepare_boxes(raw, camera, velo_to_cam, keep_all=keep_all_boxes)
         image_path = os.path.join(kitti360_path, "data_2d_raw", sequence, f"image_{cam_id:02d}",
                                   "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
         if not os.path.isfile(image_path):
@@ -596,6 +686,31 @@ def process_frame(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_p
         r["remaining_points"] = r["points_valid"][~r["bg_assigned"]]
         r["matched_pairs"] = match_detections_to_bboxes(item.boxes_2d, item.bboxes_3d, item.colors, camera)
         print(f"Visualizing frame {r['frame']} with {sum(len(s) > 0 for s in r['car_point_sets']) + 1 + len(r['matched_pairs'])} objects")
+        if visualizer is not None:
+            visualizer(r["frame"], r["car_point_sets"], item.colors, r["remaining_points"], r["matched_pairs"])
+        results.append(r)
+    return results
+
+
+def projectVeloToImage(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None, visualizer=None,
+                       frames=None, device=0):
+    """V5's entry point (V5:419-571): every annotated box (no visibility filter), depth < 30 clip,
+    per-mask point sets, ``bg_assigned`` and the score + Hungarian box matching; ``visualizer`` receives
+    (frame, car_point_sets, colors, remaining_points, matched_pairs) instead of the Open3D window."""
+    if segmenter is None:
+        raise ValueError("projectVeloToImage needs the segmentation callable")
+    root = kitti360_path or os.environ["KITTI360_DATASET"]
+    _, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames,
+                                 keep_all_boxes=True)
+    results = []
+    for r, item in zip(run_frames(items, velo_to_rect, camera, 30.0, 10, True, 0, False, device), items):
+        print(f"[DEBUG] Frame {r['frame']}: {r['n_valid']} points passed validation filter")
+        if r["n_valid"] == 0:
+            print(f"[WARN] No valid LiDAR points in frame {r['frame']}")
+            continue
+        r["remaining_points"] = r["points_valid"][~r["bg_assigned"]]
+        r["matched_pairs"] = improved_match_detections_to_bboxes(item.boxes_2d, item.bboxes_3d, item.colors, camera)
         if visualizer is not None:
             visualizer(r["frame"], r["car_point_sets"], item.colors, r["remaining_points"], r["matched_pairs"])
         results.append(r)

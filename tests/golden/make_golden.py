@@ -147,6 +147,7 @@ def main():
     v3 = _load_ref("V3_point_cloud_with_erosion.py", "ref_v3")
     v4 = _load_ref("V4_BBox_IoU_filtering.py", "ref_v4")
     cvs = _load_ref("cvs_erosion.py", "ref_cvs")
+    v5 = _load_ref("V5_ProjectingBBoxes.py", "ref_v5")
     os.environ["KITTI360_DATASET"] = DATA
 
     camera = kitti360.CameraPerspective(DATA, SEQ, 0)
@@ -270,6 +271,10 @@ def main():
             pairs = v4.match_detections_to_bboxes(boxes2d, boxes3d, colors, camera)
             out["iou_match_corners_" + kind] = np.array([p[0] for p in pairs], np.float64).reshape(-1, 8, 3)
             out["iou_match_color_" + kind] = np.array([p[1] for p in pairs], np.float64).reshape(-1, 3)
+            # V5 score + Hungarian matching (V5:307-416), on the same box list
+            pairs5 = _quiet(v5.improved_match_detections_to_bboxes, boxes2d, boxes3d, colors, camera)
+            out["v5_match_corners_" + kind] = np.array([p[0] for p in pairs5], np.float64).reshape(-1, 8, 3)
+            out["v5_match_color_" + kind] = np.array([np.asarray(p[1], np.float64) for p in pairs5], np.float64).reshape(-1, 3)
             rec["n_masks_" + kind] = int(M)
         index["frames"].append(rec)
         np.savez_compressed(os.path.join(HERE, "frame_%010d.npz" % frame), **out)

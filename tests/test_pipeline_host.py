@@ -122,3 +122,16 @@ def test_calibration_reader_known_answers(tmp_path):
     assert u[0] == int(np.round((552.554261 * 1.0 + 682.049453 * 2.0) / 2.0)) and v[2] == int(np.round((552.554261 + 238.769549 * 4.0) / 4.0))
     with pytest.raises(RuntimeError):
         kitti360.Kitti360Viewer3DRaw(seq=0, root_dir=str(tmp_path)).loadVelodyneData(5)
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+@pytest.mark.parametrize("kind", ["rect5", "edge"])
+def test_v5_score_hungarian_matching_matches_reference(rec, kind, calib):
+    g = load_golden(rec["frame"])
+    cam = _camera(calib)
+    vis = pipeline.transform_bboxes_to_velodyne(pipeline.filter_visible_bboxes(_raw_boxes(g), cam), calib["TrVeloToCam"])
+    boxes2d = g["boxes2d_" + kind]
+    with contextlib.redirect_stdout(io.StringIO()):
+        pairs = pipeline.improved_match_detections_to_bboxes(boxes2d, vis, pipeline.default_colors(len(boxes2d)), cam)
+    assert np.array_equal(np.array([p[0] for p in pairs]).reshape(-1, 8, 3), g["v5_match_corners_" + kind])
+    assert np.array_equal(np.array([np.asarray(p[1], np.float64) for p in pairs]).reshape(-1, 3), g["v5_match_color_" + kind])
