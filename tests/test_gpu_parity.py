@@ -382,3 +382,47 @@ def test_hipgraph_replay_matches_oracle(calib):
             assert np.array_equal(sm["best_box"][:M], ref["best_box"])
         ctx.graph_destroy(g)
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["u8", "f32_v3"])
+@pytest.mark.parametrize("iters", [0, 1, 2])
+def test_odd_image_size_takes_the_lds_tile_pack(ctx, mode, iters):
+    """W*H not a multiple of 16 -> the general LDS-tile pack (fused first erosion) instead of the
+    16-pixel streaming pack; the projection is then checked on that image too."""
+    rng = np.random.default_rng(17)
+    W, H, M = 77, 45, 11                                  # 11 masks -> uint16 label image
+    base = (rng.random((M, H, W)) < 0.85).astype(np.uint8)
+    base[0] = 1
+    T = np.eye(4)
+    K = np.array([[30.0, 0, W / 2], [0, 30.0, H / 2], [0, 0, 1.0]])
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    if mode == "u8":
+        ctx.set_masks(base, erode_iters=iters)
+        member = base
+    else:
+        m = base.astype(np.float32)
+        ctx.set_masks(m, erode_iters=iters, v3_pipeline=True)
+        member = orc.binarize_f32(m, 1)
+    want = orc.pack_masks(member, iters, H, W)
+    assert np.array_equal(ctx.get_label_image()[0], want)
+    pts = np.zeros((20000, 4), np.float32)
+    pts[:, 0] = rng.uniform(-4, 4, len(pts)); pts[:, 1] = rng.uniform(-3, 3, len(pts)); pts[:, 2] = rng.uniform(0.5, 6, len(pts))
+    ctx.clear_boxes()
+    r = ctx.run(pts, want_float=False)
+    o = orc.run(pts, T, K, W, H, 0.0, 50.0, label_img=want, M=M, want_float=False)
+    _compare(r, o, M, want_float=False)
+
+
+def test_frame_with_more_than_1024_segments(ctx, calib):
+    """4.6 M points in ONE frame = 1123 segments: the general (two-phase) segment scan instead of the
+    register-resident one; masks and boxes on, every list compared."""
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    sc = S.scene(4_600_000, n_masks=4, n_boxes=6, seed=77)
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    ctx.set_masks(sc["masks"])
+    ctx.set_boxes(sc["corners_velo"])
+    r = ctx.run(sc["points"], want_float=False)
+    lab = orc.pack_masks(sc["masks"], 0, H, W)
+    o = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=lab, M=4, corners=sc["corners_velo"], want_float=False)
+    _compare(r, o, 4, want_float=False)

@@ -214,3 +214,60 @@ def test_depth_image_and_per_car_depth_maps(calib):
     D, win = ctx.depth_image(pts)
     Dref, wref = orc.depth_image(pts, calib["TrVeloToRect"], calib["K"][:, :3], cam.width, cam.height, 0.0, 50.0)
     assert np.array_equal(D, Dref) and np.array_equal(win, wref)
+
+
+def _dataset_tree(tmp_path, calib, frames_wanted):
+    cam = _camera(calib)
+    root = tmp_path / "KITTI360_sample"
+    seq = "2013_05_28_drive_0000_sync"
+    (root / "data_3d_raw" / seq / "velodyne_points" / "data").mkdir(parents=True)
+    (root / "bboxes_3D_cam0").mkdir()
+    (root / "data_2d_raw" / seq / "image_00" / "data_rect").mkdir(parents=True)
+    gold = {}
+    for r in golden_frames()["frames"]:
+        if r["frame"] not in frames_wanted:
+            continue
+        g = load_golden(r["frame"])
+        g["points"].tofile(str(root / "data_3d_raw" / seq / "velodyne_points" / "data" / ("%010d.bin" % r["frame"])))
+        (root / "data_2d_raw" / seq / "image_00" / "data_rect" / ("%010d.png" % r["frame"])).write_bytes(b"")
+        if "skipped" in r:
+            continue
+        raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
+        (root / "bboxes_3D_cam0" / ("BBoxes_%d.json" % r["frame"])).write_text(json.dumps(raw))
+        gold[r["frame"]] = g
+    velo = kitti360.Kitti360Viewer3DRaw(seq=0, root_dir=str(root))
+    return root, seq, cam, velo, gold
+
+
+def test_v3_v4_v5_entry_points(calib, tmp_path, monkeypatch):
+    """process_frame_with_statistics (V3), process_frame (V4), projectVeloToImage (V5) on a rebuilt dataset tree."""
+    root, seq, cam, velo, gold = _dataset_tree(tmp_path, calib, (100, 1461, 2717))
+    monkeypatch.setattr(pipeline, "sequence_setup",
+                        lambda path, s=0, c=0: (seq, cam, calib["TrVeloToCam"], calib["TrVeloToRect"], velo))
+
+    def segmenter(image_path):
+        frame = int(os.path.basename(image_path).split(".")[0])
+        m = unpack_masks(gold[frame], "rect5", cam.height, cam.width)
+        return None, m, pipeline.default_colors(len(m)), gold[frame]["boxes2d_rect5"], np.ones(len(m))
+
+    seen = {}
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        res3 = pipeline.process_frame_with_statistics(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root),
+                                                      visualizer=lambda f, st, pv, bg: seen.setdefault(f, (st, pv, bg)))
+    assert [r["frame"] for r in res3] == [100, 1461] and "SUMMARY STATISTICS" in out.getvalue()
+    for r in res3:
+        g = gold[r["frame"]]
+        assert [d["points_inside_bbox"] for d in r["car_statistics"]] == g["stats_points_inside_bbox_rect5_d50"].tolist()
+        st, pv, bg = seen[r["frame"]]
+        assert len(pv) == len(g["valid_idx_d50"]) and bg.sum() == np.unpackbits(g["bg_assigned_rect5_d50"])[:len(pv)].sum()
+    with contextlib.redirect_stdout(io.StringIO()):
+        res4 = pipeline.process_frame(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root))
+        res5 = pipeline.projectVeloToImage(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root))
+    for r4, r5 in zip(res4, res5):
+        g = gold[r4["frame"]]
+        assert np.array_equal(r4["valid_indices"], g["valid_idx_d30"]) and np.array_equal(r5["valid_indices"], g["valid_idx_d30"])
+        assert [len(s) for s in r4["car_point_sets"]] == g["inst_count_rect5_d30"].tolist()
+        assert len(r4["remaining_points"]) == len(g["valid_idx_d30"]) - np.unpackbits(g["bg_assigned_rect5_d30"])[:len(g["valid_idx_d30"])].sum()
+        assert np.array_equal(np.array([p[0] for p in r4["matched_pairs"]]).reshape(-1, 8, 3), g["iou_match_corners_rect5"])
+        # V5 keeps every annotated box: all of them come back (matched in colour or grey)
+        assert len(r5["matched_pairs"]) == len(g["corners_cam0_raw"])
