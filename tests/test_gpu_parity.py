@@ -426,3 +426,62 @@ def test_frame_with_more_than_1024_segments(ctx, calib):
     lab = orc.pack_masks(sc["masks"], 0, H, W)
     o = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=lab, M=4, corners=sc["corners_velo"], want_float=False)
     _compare(r, o, 4, want_float=False)
+
+
+def test_error_codes_are_loud(calib):
+    """No silent fallbacks: wrong call order / shapes give LpfError with the library's message."""
+    from lidar_object_detection_amd._native import LpfContext, LpfError
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    c = LpfContext(0)
+    pts = S.synthetic_cloud(1000, seed=1)
+    with pytest.raises(LpfError, match="set_camera"):
+        c.run(pts)
+    with pytest.raises(LpfError, match="set_camera"):
+        c.set_masks(np.zeros((1, 8, 8), np.uint8)) if False else c._check(c._lib.lpf_set_masks_u8(c._h, None, 1, 1, 0, 0))
+    c.set_camera(T, K, W, H, 0.0, 50.0)
+    with pytest.raises(ValueError):
+        c.set_masks(np.zeros((2, H + 1, W), np.uint8))                      # wrong image size (wrapper check)
+    with pytest.raises(LpfError, match="M=33"):
+        c._check(c._lib.lpf_set_masks_u8(c._h, np.zeros((33, H, W), np.uint8).ctypes.data, 1, 33, 0, 0))
+    c.set_masks(np.zeros((2, 3, H, W), np.uint8))                           # masks for 2 frames ...
+    with pytest.raises(LpfError, match="masks were set for 2 frames"):
+        c.run(pts)                                                          # ... but a 1-frame run
+    c.clear_masks()
+    c.set_boxes([np.zeros((1, 8, 3)), np.zeros((2, 8, 3))])
+    with pytest.raises(LpfError, match="boxes were set for 2 frames"):
+        c.run(pts)
+    c.clear_boxes()
+    r = c.run(pts)                                                           # and it still works afterwards
+    assert r["n_valid"] == orc.run(pts, T, K, W, H, 0.0, 50.0, want_float=False)["n_valid"]
+    with pytest.raises(LpfError, match="inst_cap"):
+        from lidar_object_detection_amd._native import Outputs
+        import ctypes
+        o = Outputs(); o.inst_idx = 1; o.inst_cap = 0
+        c._check(c._lib.lpf_run(c._h, pts.ctypes.data, 1000, 0, ctypes.byref(o)))
+    c.close()
+
+
+def test_degenerate_boxes_and_nan_points(ctx, calib):
+    """Zero-size and NaN boxes (vv == 0 / NaN: the reference's division gives nan/inf -> outside), NaN / inf
+    points: exact agreement with the oracle, no fault."""
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    sc = S.scene(60000, n_masks=3, n_boxes=5, seed=88)
+    corners = sc["corners_velo"].copy()
+    corners[1] = corners[1][0]                           # all 8 corners identical: vv = 0 on every axis
+    corners[2][3] = corners[2][0]                        # one degenerate axis
+    corners[3][4, 0] = np.nan
+    pts = sc["points"].copy()
+    pts[::97, 0] = np.nan
+    pts[5::101, 2] = np.inf
+    pts[7::103, 1] = -np.inf
+    masks = sc["masks"].copy()
+    masks[0] = 1
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    ctx.set_masks(masks)
+    ctx.set_boxes(corners)
+    r = ctx.run(pts, want_float=True)
+    lab = orc.pack_masks(masks, 0, H, W)
+    o = orc.run(pts, T, K, W, H, 0.0, 50.0, label_img=lab, M=3, corners=corners)
+    _compare(r, o, 3)
