@@ -103,12 +103,14 @@ int lpf_set_camera(lpf_ctx *ctx, const double T_velo_to_rect[16], const double K
 /* ---- per-frame (or per-batch) state --------------------------------------------
  * Masks of F frames, M <= 32 per frame (pad with all-zero masks), each H x W.
  * u8: nonzero = member.  f32: the reference's float masks;
- *   v3_pipeline = 0 : member <=> mask.astype(np.uint8) != 0                  (V3:222-225 on raw masks, V2/V4)
- *   v3_pipeline = 1 : (mask*255).astype(uint8) -> erode -> /255.0 -> astype(uint8) != 0   (V3:82-97 then V3:222)
+ *   binarize = 0 : member <=> mask.astype(np.uint8) != 0                  (V3:222-225 on raw masks, V2/V4)
+ *   binarize = 1 : (mask*255).astype(uint8) -> erode -> /255.0 -> astype(uint8) != 0   (V3:82-97 then V3:222)
+ *   binarize = 2 : member <=> mask > 0.5 on the raw float mask   (Same_color.py:125, vis.py:185,
+ *                  seg_with_pointcloud.py:167: the scripts that index the YOLO mask without astype)
  * erode_iters: iterations of cv2.erode with the 3x3 MORPH_ELLIPSE (cross) element (V3:83-90).
  * The packed result is a uint32 label image [F][H][W], bit m = mask m, kept in HBM. */
 int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode_iters, int on_device);
-int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int v3_pipeline,
+int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int binarize,
                       int erode_iters, int on_device);
 /* Pre-packed label images [F][H][W] (bit m = mask m). */
 int lpf_set_label_image(lpf_ctx *ctx, const uint32_t *label, int F, int M, int on_device);

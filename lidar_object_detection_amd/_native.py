@@ -194,9 +194,17 @@ class LpfContext:
                                              float(depth_min), float(depth_max)))
         self.W, self.H = int(width), int(height)
 
-    def set_masks(self, masks, erode_iters=0, v3_pipeline=False):
+    BINARIZE = {"astype": 0, "v3": 1, "gt0.5": 2}
+
+    def set_masks(self, masks, erode_iters=0, v3_pipeline=False, binarize=None):
         """masks: [M,H,W] or [F,M,H,W]; uint8/bool (nonzero = member) or float32 (reference masks).
-        NumPy array, or torch tensor already on the GPU."""
+        NumPy array, or torch tensor already on the GPU.  Float masks: ``binarize`` is "astype"
+        (mask.astype(uint8) != 0, V3:222-225), "v3" (the V3:82-97 erosion block's casts; same as
+        v3_pipeline=True) or "gt0.5" (mask > 0.5, Same_color.py:125 / vis.py:185)."""
+        if binarize is None:
+            binarize = "v3" if v3_pipeline else "astype"
+        if binarize not in self.BINARIZE:
+            raise ValueError("binarize must be one of %s" % sorted(self.BINARIZE))
         dev = _is_torch(masks)
         shape = tuple(masks.shape)
         if len(shape) == 3:
@@ -217,7 +225,7 @@ class LpfContext:
             ptr = a.ctypes.data if M else None
             keep = a
         if is_f:
-            rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, int(bool(v3_pipeline)), int(erode_iters), int(dev))
+            rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, self.BINARIZE[binarize], int(erode_iters), int(dev))
         else:
             rc = self._lib.lpf_set_masks_u8(self._h, ptr, F, M, int(erode_iters), int(dev))
         del keep

@@ -306,8 +306,10 @@ int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks
                 hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
             else if (mode == 1)
                 hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
-            else
+            else if (mode == 2)
                 hipLaunchKernelGGL((lpf_pack16<T, 2, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+            else
+                hipLaunchKernelGGL((lpf_pack16<T, 3, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
         } else {
             const int fuse = erode_iters > 0 ? 1 : 0;
             left -= fuse;
@@ -315,8 +317,10 @@ int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks
                 hipLaunchKernelGGL((lpf_pack_erode<T, 0, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
             else if (mode == 1)
                 hipLaunchKernelGGL((lpf_pack_erode<T, 1, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
-            else
+            else if (mode == 2)
                 hipLaunchKernelGGL((lpf_pack_erode<T, 2, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+            else
+                hipLaunchKernelGGL((lpf_pack_erode<T, 3, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
         }
         LPF_HIP(c, hipGetLastError());
         if (left > 0) {
@@ -495,9 +499,10 @@ int lpf_set_masks_u8(lpf_ctx *c, const uint8_t *masks, int F, int M, int erode_i
     return set_masks_impl<uint8_t>(c, masks, F, M, 0, erode_iters, on_device);
 }
 
-int lpf_set_masks_f32(lpf_ctx *c, const float *masks, int F, int M, int v3_pipeline, int erode_iters, int on_device)
+int lpf_set_masks_f32(lpf_ctx *c, const float *masks, int F, int M, int binarize, int erode_iters, int on_device)
 {
-    return set_masks_impl<float>(c, masks, F, M, v3_pipeline ? 2 : 1, erode_iters, on_device);
+    if (c && (binarize < 0 || binarize > 2)) return fail(c, LPF_ERR_ARG, "lpf_set_masks_f32: binarize=%d (0, 1 or 2)", binarize);
+    return set_masks_impl<float>(c, masks, F, M, binarize + 1, erode_iters, on_device);
 }
 
 int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_device)

@@ -845,6 +845,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const double *_
 // ------------------------------------------------------------------------------------
 // K8: masks -> label image.
 //   MODE 0: uint8, nonzero.  MODE 1: float, astype(uint8) != 0.  MODE 2: float, (x*255) -> u8 == 255.
+//   MODE 3: float, x > 0.5 (NaN is not a member).
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lpf_f32_to_u8(float v)
 {
@@ -858,6 +859,7 @@ __device__ __forceinline__ bool lpf_member(T v)
 {
     if (MODE == 0) return v != 0;
     if (MODE == 1) return lpf_f32_to_u8((float)v) != 0u;
+    if (MODE == 3) return (float)v > 0.5f;
     return lpf_f32_to_u8((float)v * 255.0f) == 255u;
 }
 

@@ -434,6 +434,144 @@ def improved_match_detections_to_bboxes(boxes_2d, bboxes_3d, mask_colors, camera
 
 
 # ---------------------------------------------------------------------------------------
+# box-view helpers of secondtest.py / V5 / firsttest.py (8 corners per box: host scalars)
+# ---------------------------------------------------------------------------------------
+_HSV_SECTORS = ((0, 3, 1), (2, 0, 1), (1, 0, 3), (1, 2, 0), (3, 1, 0), (0, 1, 2))   # (r, g, b) picks from (value, p, q, t)
+
+
+def generate_consistent_colors(n_objects):
+    """BGR 0-255 tuples, golden-angle hues (V5:88-121): hue = i*137.508 mod 360,
+    saturation 0.8 + 0.1*(i%3), value 0.8 + 0.2*(i%2)."""
+    out = []
+    for i in range(n_objects):
+        hue = (i * 137.508) % 360
+        sat, val = 0.8 + (i % 3) * 0.1, 0.8 + (i % 2) * 0.2
+        sector = int(hue / 60) % 6
+        frac = (hue / 60) - sector
+        comp = (val, val * (1 - sat), val * (1 - frac * sat), val * (1 - (1 - frac) * sat))
+        r, g, b = (comp[k] for k in _HSV_SECTORS[sector])
+        out.append((int(b * 255), int(g * 255), int(r * 255)))
+    return out
+
+
+def project_3d_bbox_to_2d(bbox_3d, camera, detailed=True):
+    """Image-plane box of the corners with depth > 0.  detailed=True: V5:215-252 /
+    secondtest.py:215-252 -> ({'bbox','center','size','area','avg_depth'}, corners_cam0);
+    detailed=False: firsttest.py:172-193 -> ([x_min, y_min, x_max, y_max], corners_cam0).
+    (None, None) when nothing is in front of the camera or the dict has no corners."""
+    try:
+        corners = np.array(bbox_3d["corners_cam0"])
+        u, v, depth = camera.cam2image(corners.T)
+        front = depth > 0
+        if np.any(front):
+            x0, x1 = np.min(u[front]), np.max(u[front])
+            y0, y1 = np.min(v[front]), np.max(v[front])
+            if not detailed:
+                return [x0, y0, x1, y1], corners
+            return {"bbox": [x0, y0, x1, y1], "center": [(x0 + x1) / 2, (y0 + y1) / 2], "size": [x1 - x0, y1 - y0],
+                    "area": (x1 - x0) * (y1 - y0), "avg_depth": np.mean(depth[front])}, corners
+    except Exception as e:
+        print(f"[ERROR] Failed to project 3D bbox: {e}")
+    return None, None
+
+
+def is_bbox_in_camera_view(bbox_3d, camera, min_points_in_view=4, depth_range=(0.1, 100)):
+    """(keep, info) of secondtest.py:277-359.  Corners count when depth lies in the closed
+    depth_range; a box is dropped when none do ('all_behind_camera'), when fewer than
+    min_points_in_view corners are inside the image AND the corners' pixel box misses the image
+    ('no_intersection'), or when that pixel box is under 100 px^2 ('too_small')."""
+    try:
+        if "corners_cam0" not in bbox_3d:
+            return False, {"reason": "no_corners"}
+        u, v, depth = camera.cam2image(np.array(bbox_3d["corners_cam0"]).T)
+        near = (depth >= depth_range[0]) & (depth <= depth_range[1])
+        n_near = np.sum(near)
+        if n_near == 0:
+            return False, {"reason": "all_behind_camera", "depths": depth.tolist()}
+        in_view = np.sum(near & (u >= 0) & (u < camera.width) & (v >= 0) & (v < camera.height))
+        un, vn = u[near], v[near]
+        if in_view < min_points_in_view:
+            x0, x1, y0, y1 = np.min(un), np.max(un), np.min(vn), np.max(vn)
+            if x1 < 0 or x0 >= camera.width or y1 < 0 or y0 >= camera.height:
+                return False, {"reason": "no_intersection", "corners_in_view": in_view, "bbox_2d": [x0, y0, x1, y1]}
+        if n_near >= 2:
+            u_range, v_range = np.max(un) - np.min(un), np.max(vn) - np.min(vn)
+            if u_range * v_range < 100:
+                return False, {"reason": "too_small", "projected_area": u_range * v_range,
+                               "u_range": u_range, "v_range": v_range}
+        return True, {"reason": "valid", "corners_in_view": in_view, "corners_with_valid_depth": n_near,
+                      "avg_depth": np.mean(depth[near]) if n_near > 0 else 0}
+    except Exception as e:
+        print(f"[ERROR] Error checking bbox visibility: {e}")
+        return False, {"reason": "error", "error": str(e)}
+
+
+def filter_bboxes_in_camera_view(bboxes_3d, camera, verbose=True):
+    """(kept boxes in order, {'total','kept','filtered','filter_reasons'}) -- secondtest.py:362-419."""
+    if not bboxes_3d:
+        return [], {"total": 0, "kept": 0, "filtered": 0, "filter_reasons": {}}
+    kept, reasons = [], {}
+    for i, bbox in enumerate(bboxes_3d):
+        ok, info = is_bbox_in_camera_view(bbox, camera)
+        if ok:
+            kept.append(bbox)
+            if verbose:
+                print(f"[INFO] Kept bbox {i}: {info['corners_in_view']} corners in view, "
+                      f"avg depth: {info.get('avg_depth', 0):.2f}m")
+            continue
+        why = info["reason"]
+        reasons[why] = reasons.get(why, 0) + 1
+        if verbose:
+            print(f"[INFO] Filtered bbox {i}: {why}")
+            if why == "all_behind_camera" and info.get("depths"):
+                print(f"        Depths: min={min(info['depths']):.2f}, max={max(info['depths']):.2f}")
+            elif why == "no_intersection":
+                print(f"        2D bbox: {info.get('bbox_2d', [])}")
+            elif why == "too_small":
+                print(f"        Projected area: {info.get('projected_area', 0):.1f} pixels")
+    stats = {"total": len(bboxes_3d), "kept": len(kept), "filtered": len(bboxes_3d) - len(kept), "filter_reasons": reasons}
+    if verbose:
+        print(f"\n[STATS] BBox Filtering Results:")
+        print(f"        Total: {stats['total']}")
+        print(f"        Kept: {stats['kept']}")
+        print(f"        Filtered: {stats['filtered']}")
+        print(f"        Filter reasons: {stats['filter_reasons']}")
+    return kept, stats
+
+
+# ---------------------------------------------------------------------------------------
+# exclusive labelling of Same_color.py:113-131 (first matching mask wins)
+# ---------------------------------------------------------------------------------------
+def label_points_first_match(points, TrVeloToRect, camera, masks, mask_colors=None, depth_max=30.0, device=0):
+    """Same_color.py's per-point double loop as one fused GPU pass.  Returns a dict:
+    ``car_idx`` (indices into points of valid points that lie in some mask, ascending),
+    ``car_mask`` (the FIRST mask each of them matched, ``mask[y, x] > 0.5``), ``background_idx``
+    (valid points in no mask), and ``colored_points`` / ``colored_colors`` / ``full_points`` as the
+    reference accumulates them (colors = mask_colors[i] / 255.0 when mask_colors is given)."""
+    p = _f32_points(points).reshape(-1, 4)
+    m = _mask_stack(masks, camera)
+    if m.shape[0] > LPF_MAX_MASKS:
+        raise ValueError("at most %d masks per frame" % LPF_MAX_MASKS)
+    ctx = get_context(device)
+    ctx.set_camera(TrVeloToRect, camera.K, camera.width, camera.height, 0.0, float(depth_max))
+    ctx.set_masks(m, binarize="gt0.5")
+    ctx.clear_boxes()
+    r = ctx.run(p, want_uv=False)
+    ctx.clear_masks()
+    vidx = r["valid_idx"]
+    bits = r["label_bits"][vidx]
+    hit = bits != 0
+    low = bits[hit] & (~bits[hit] + np.uint32(1))                       # lowest set bit = first mask in list order
+    first = np.log2(low.astype(np.float64)).astype(np.int64) if low.size else np.zeros(0, np.int64)
+    out = {"car_idx": vidx[hit], "car_mask": first, "background_idx": vidx[~hit],
+           "colored_points": p[vidx[hit], :3], "full_points": p[vidx[~hit], :3]}
+    if mask_colors is not None:
+        table = np.array([np.array(c) / 255.0 for c in mask_colors], np.float64).reshape(-1, 3)
+        out["colored_colors"] = table[first]
+    return out
+
+
+# ---------------------------------------------------------------------------------------
 # reporting (V3:431-468, cvs_erosion.py:232-295)
 # ---------------------------------------------------------------------------------------
 def print_summary_statistics(car_statistics):

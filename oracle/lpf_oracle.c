@@ -122,12 +122,14 @@ static inline uint8_t orc_f32_to_u8(float f)
 /* member(m, pixel) for float masks.
  *   v3_erosion == 0 (V2/V4: V3:222-225 on raw masks):  astype(uint8) != 0
  *   v3_erosion == 1 (V3:87):  (mask*255).astype(uint8) == 255 survives
- *                              erode -> /255.0 -> astype(uint8) != 0           */
+ *                              erode -> /255.0 -> astype(uint8) != 0
+ *   v3_erosion == 2 (Same_color.py:125, vis.py:185, seg_with_pointcloud.py:167):  mask[y, x] > 0.5   */
 void orc_binarize_f32(const float *masks, int64_t n, int v3_erosion, uint8_t *out)
 {
     for (int64_t i = 0; i < n; ++i) {
-        if (v3_erosion) out[i] = (orc_f32_to_u8(masks[i] * 255.0f) == 255) ? 1 : 0;
-        else            out[i] = (orc_f32_to_u8(masks[i]) != 0) ? 1 : 0;
+        if (v3_erosion == 2)      out[i] = (masks[i] > 0.5f) ? 1 : 0;
+        else if (v3_erosion == 1) out[i] = (orc_f32_to_u8(masks[i] * 255.0f) == 255) ? 1 : 0;
+        else                      out[i] = (orc_f32_to_u8(masks[i]) != 0) ? 1 : 0;
     }
 }
 

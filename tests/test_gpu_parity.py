@@ -182,7 +182,7 @@ def test_constructed_edge_points(ctx):
         assert np.array_equal(r[k], o[k], equal_nan=True)
 
 
-@pytest.mark.parametrize("mode", ["u8", "f32_raw", "f32_v3"])
+@pytest.mark.parametrize("mode", ["u8", "f32_raw", "f32_v3", "f32_gt"])
 @pytest.mark.parametrize("iters", [0, 1, 2, 3])
 def test_mask_pack_and_erosion(ctx, calib, mode, iters):
     rng = np.random.default_rng(3)
@@ -199,10 +199,10 @@ def test_mask_pack_and_erosion(ctx, calib, mode, iters):
         member = base
     else:
         m = base.astype(np.float32)
-        m[3] *= rng.choice(np.array([0.0, 0.5, 0.999, 1.0, 1.5, 2.0], np.float32), size=(H, W))
-        v3 = mode == "f32_v3"
-        ctx.set_masks(m, erode_iters=iters, v3_pipeline=v3)
-        member = orc.binarize_f32(m, 1 if v3 else 0)
+        m[3] *= rng.choice(np.array([0.0, 0.5, 0.50000006, 0.999, 1.0, 1.5, 2.0, 256.0, np.nan, -1.0], np.float32), size=(H, W))
+        b = {"f32_raw": "astype", "f32_v3": "v3", "f32_gt": "gt0.5"}[mode]
+        ctx.set_masks(m, erode_iters=iters, binarize=b)
+        member = orc.binarize_f32(m, {"astype": 0, "v3": 1, "gt0.5": 2}[b])
     want = orc.pack_masks(member, iters, H, W)
     assert np.array_equal(ctx.get_label_image()[0], want)
 

@@ -271,3 +271,24 @@ def test_v3_v4_v5_entry_points(calib, tmp_path, monkeypatch):
         assert np.array_equal(np.array([p[0] for p in r4["matched_pairs"]]).reshape(-1, 8, 3), g["iou_match_corners_rect5"])
         # V5 keeps every annotated box: all of them come back (matched in colour or grey)
         assert len(r5["matched_pairs"]) == len(g["corners_cam0_raw"])
+
+
+def test_first_match_labelling_matches_same_color_loop(calib):
+    """Same_color.py:113-131 (exclusive, first mask wins, mask > 0.5, depth < 30) on frame 100 with the
+    nine overlapping 'edge' masks; golden = the reference's loop run by tests/golden/make_golden_views.py."""
+    views = np.load(os.path.join(os.path.dirname(__file__), "golden", "views_golden.npz"))
+    g = load_golden(100)
+    cam = _camera(calib)
+    masks = unpack_masks(g, "edge", cam.height, cam.width)
+    masks[3] *= np.float32(0.75)                        # still > 0.5: a member here, not under astype(uint8)
+    colors = pipeline.generate_consistent_colors(len(masks))
+    r = pipeline.label_points_first_match(g["points"], calib["TrVeloToRect"], cam, masks, colors, depth_max=30)
+    assert np.array_equal(r["car_idx"], views["samecolor_idx"])
+    assert np.array_equal(r["car_mask"], views["samecolor_mask"].astype(np.int64))
+    assert np.array_equal(r["background_idx"], views["samecolor_bg"])
+    assert np.array_equal(r["colored_points"], g["points"][views["samecolor_idx"], :3])
+    assert np.array_equal(r["full_points"], g["points"][views["samecolor_bg"], :3])
+    assert np.array_equal(r["colored_colors"][:64], views["samecolor_colors"])
+    assert len(set(views["samecolor_mask"].tolist())) > 3 and len(r["car_idx"]) + len(r["background_idx"]) == len(g["valid_idx_d30"])
+    empty = pipeline.label_points_first_match(g["points"][:1000], calib["TrVeloToRect"], cam, [], None, depth_max=30)
+    assert len(empty["car_idx"]) == 0 and len(empty["background_idx"]) == int(np.sum(g["valid_idx_d30"] < 1000))

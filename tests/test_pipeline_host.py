@@ -135,3 +135,93 @@ def test_v5_score_hungarian_matching_matches_reference(rec, kind, calib):
         pairs = pipeline.improved_match_detections_to_bboxes(boxes2d, vis, pipeline.default_colors(len(boxes2d)), cam)
     assert np.array_equal(np.array([p[0] for p in pairs]).reshape(-1, 8, 3), g["v5_match_corners_" + kind])
     assert np.array_equal(np.array([np.asarray(p[1], np.float64) for p in pairs]).reshape(-1, 3), g["v5_match_color_" + kind])
+
+
+# ---- secondtest.py / V5 / firsttest.py box-view helpers (tests/golden/views_golden.npz) --------------
+REASONS = ("valid", "no_corners", "all_behind_camera", "no_intersection", "too_small", "error")
+
+
+@pytest.fixture(scope="module")
+def views():
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "views_golden.npz")))
+
+
+def test_generate_consistent_colors_matches_reference(views):
+    assert pipeline.generate_consistent_colors(40) == [tuple(int(x) for x in c) for c in views["colors40"]]
+    assert pipeline.generate_consistent_colors(0) == []
+    assert all(isinstance(x, int) for c in pipeline.generate_consistent_colors(3) for x in c)
+
+
+def _view_frames(views):
+    for k, frame in enumerate(views["frames"]):
+        yield k, int(frame), int(views["box_off"][k]), int(views["box_off"][k + 1])
+
+
+def test_camera_view_filter_matches_reference(views, calib):
+    cam = _camera(calib)
+    n_checked = 0
+    for k, frame, b0, b1 in _view_frames(views):
+        raw = _raw_boxes(load_golden(frame))
+        assert len(raw) == b1 - b0
+        for j, b in enumerate(raw):
+            ok, info = pipeline.is_bbox_in_camera_view(b, cam)
+            i = b0 + j
+            assert ok == bool(views["keep"][i]) and info["reason"] == REASONS[views["reason"][i]], (frame, j)
+            if ok:
+                assert int(info["corners_in_view"]) == views["corners_in_view"][i]
+                assert int(info["corners_with_valid_depth"]) == views["corners_with_valid_depth"][i]
+                assert info["avg_depth"] == views["avg_depth"][i]                # same float, not merely close
+            elif info["reason"] == "no_intersection":
+                assert int(info["corners_in_view"]) == views["corners_in_view"][i] and len(info["bbox_2d"]) == 4
+            n_checked += 1
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            kept, stats = pipeline.filter_bboxes_in_camera_view(raw, cam, verbose=(k == 0))
+        assert stats["kept"] == views["kept_count"][k] == len(kept) and stats["total"] == len(raw)
+        assert stats["filtered"] == sum(stats["filter_reasons"].values())
+        assert [b["index"] for b in kept] == [b["index"] for b, f in zip(raw, views["keep"][b0:b1]) if f]
+        if k == 0:
+            text = buf.getvalue()
+            assert "[STATS] BBox Filtering Results:" in text and "[INFO] Kept bbox" in text and "avg depth:" in text
+    assert n_checked == len(views["keep"]) > 900
+    assert pipeline.is_bbox_in_camera_view({}, cam) == (False, {"reason": "no_corners"})
+    assert pipeline.filter_bboxes_in_camera_view([], cam) == ([], {"total": 0, "kept": 0, "filtered": 0, "filter_reasons": {}})
+
+
+def test_project_3d_bbox_to_2d_matches_reference(views, calib):
+    cam = _camera(calib)
+    for k, frame, b0, b1 in _view_frames(views):
+        for j, b in enumerate(_raw_boxes(load_golden(frame))):
+            i = b0 + j
+            info, corners = pipeline.project_3d_bbox_to_2d(b, cam)
+            plain, corners2 = pipeline.project_3d_bbox_to_2d(b, cam, detailed=False)
+            if not views["proj_ok"][i]:
+                assert info is None and corners is None and plain is None and corners2 is None
+                continue
+            assert [int(x) for x in info["bbox"]] == views["proj_bbox"][i].tolist() == [int(x) for x in plain]
+            assert list(info["center"]) == views["proj_center"][i].tolist()
+            assert [int(x) for x in info["size"]] == views["proj_size"][i].tolist()
+            assert int(info["area"]) == views["proj_area"][i] and info["avg_depth"] == views["proj_avg_depth"][i]
+            assert np.array_equal(corners, np.array(b["corners_cam0"]))
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        assert pipeline.project_3d_bbox_to_2d({}, cam) == (None, None)
+    assert "[ERROR] Failed to project 3D bbox" in buf.getvalue()
+
+
+def test_firsttest_iou_match_threshold_matches_reference(views, calib):
+    """firsttest.py:218-260 = the V4 matcher at iou_threshold 0.1, fed with shifted projections."""
+    cam = _camera(calib)
+    for k, frame, b0, b1 in _view_frames(views):
+        raw = _raw_boxes(load_golden(frame))
+        boxes3d = pipeline.transform_bboxes_to_velodyne([dict(b) for b in raw], calib["TrVeloToCam"])
+        kept = [b for b, f in zip(raw, views["keep"][b0:b1]) if f]
+        dets = []
+        for b in kept[:6]:
+            bb, _ = pipeline.project_3d_bbox_to_2d(b, cam, detailed=False)
+            dets.append([bb[0] + 3.0, bb[1] - 2.0, bb[2] + 17.0, bb[3] + 5.0])
+        dets.append([5000.0, 5000.0, 5100.0, 5100.0])
+        colors = pipeline.generate_consistent_colors(len(dets))
+        pairs = pipeline.match_detections_to_bboxes(np.array(dets, np.float32), boxes3d, colors, cam, min_iou=0.1)
+        m0, m1 = int(views["first_match_off"][k]), int(views["first_match_off"][k + 1])
+        assert len(pairs) == m1 - m0
+        for (c, col), wc, wcol in zip(pairs, views["first_match_corners"][m0:m1], views["first_match_color"][m0:m1]):
+            assert np.array_equal(c, wc) and np.array_equal(col, wcol)
