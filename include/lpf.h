@@ -39,7 +39,8 @@ typedef enum lpf_status {
     LPF_ERR_ARG = -1,             /* bad argument (null, negative, M > 32, ...) */
     LPF_ERR_HIP = -2,             /* a HIP runtime call failed */
     LPF_ERR_STATE = -3,           /* camera / masks / boxes not set for this call */
-    LPF_ERR_NOMEM = -4            /* device or host allocation failed */
+    LPF_ERR_NOMEM = -4,           /* device or host allocation failed */
+    LPF_ERR_IO = -5               /* a scan file is missing, truncated or not [N][4] float32 (lpf_reader_*) */
 } lpf_status;
 
 typedef struct lpf_ctx lpf_ctx;
@@ -180,6 +181,31 @@ void lpf_graph_destroy(lpf_graph *g);
  * since the last reset.  (No reference counterpart: the reference has no timers.) */
 int lpf_profile_enable(lpf_ctx *ctx, int on);
 int lpf_profile_read(lpf_ctx *ctx, double *k1_ms_sum, int64_t *k1_launches, int reset);
+
+/* ---- scan reader ------------------------------------------------------------------------------
+ * Double-buffered velodyne .bin reader for frame loops and the 10 Hz stream.  Stands where the
+ * reference calls Kitti360Viewer3DRaw.loadVelodyneData once per frame (V3:24-28, V3:545:
+ * np.fromfile(path, float32).reshape(-1, 4); RuntimeError('<path> does not exist!') when missing):
+ * a worker thread reads the submitted files, in order, into pinned host memory and an internal
+ * copy stream moves them to HBM while earlier scans are being processed.
+ *   lpf_reader_create  n_buffers in [2,16] scans in flight, each up to max_points points.
+ *   lpf_reader_submit  enqueue a file (returns at once; any number may be outstanding).
+ *   lpf_reader_next    the oldest submitted scan: *d_pts = its HBM copy (pass to lpf_run* with
+ *                      pts_on_device = 1), *h_pts = the pinned host copy (the array the reference
+ *                      would hold; for host-side gathers), *n_points = N.  The context's stream
+ *                      waits on the device for the copy; the host does not block on PCIe.  Pointers
+ *                      stay valid until the next lpf_reader_next on this reader (work already enqueued
+ *                      on the context's stream may still use them after that).  A missing / malformed
+ *                      file gives LPF_ERR_IO for that scan (lpf_last_error names it) and the reader
+ *                      carries on with the following one.
+ *   lpf_reader_wait    host-side wait for the copy of the scan handed out last (only for callers that
+ *                      touch *d_pts outside the context's stream). */
+typedef struct lpf_reader lpf_reader;
+int  lpf_reader_create(lpf_ctx *ctx, lpf_reader **out, int n_buffers, int64_t max_points);
+int  lpf_reader_submit(lpf_reader *rd, const char *path);
+int  lpf_reader_next(lpf_reader *rd, const float **d_pts, const float **h_pts, int64_t *n_points);
+int  lpf_reader_wait(lpf_reader *rd);
+void lpf_reader_destroy(lpf_reader *rd);
 
 #ifdef __cplusplus
 }

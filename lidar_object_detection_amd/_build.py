@@ -10,12 +10,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liblpf.so")
-SOURCES = ("lpf_api.hip", "lpf_kernels.hip.h")
+SOURCES = ("lpf_api.hip", "lpf_kernels.hip.h", "lpf_reader.hip.h")
 ARCH = "gfx950"
 
 # -ffp-contract=off: the kernels spell out every fma() the reference's BLAS performs;
 # the compiler must not fuse (or split) anything else, or integer outputs can flip.
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

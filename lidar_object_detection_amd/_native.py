@@ -86,6 +86,12 @@ def load():
     lib.lpf_graph_destroy.restype = None
     lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
     lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
+    lib.lpf_reader_create.argtypes = [_P, ctypes.POINTER(_P), ctypes.c_int, _I64]
+    lib.lpf_reader_submit.argtypes = [_P, ctypes.c_char_p]
+    lib.lpf_reader_next.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I64)]
+    lib.lpf_reader_wait.argtypes = [_P]
+    lib.lpf_reader_destroy.argtypes = [_P]
+    lib.lpf_reader_destroy.restype = None
     _lib = lib
     return lib
 
@@ -94,7 +100,8 @@ EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "l
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read",
-            "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy")
+            "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
+            "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
 
 
 def _is_torch(x):
@@ -110,6 +117,88 @@ def _dev_ptr(t, dtype_name=None):
     if dtype_name is not None and str(t.dtype) != "torch." + dtype_name:
         raise ValueError("expected torch.%s, got %s" % (dtype_name, t.dtype))
     return t.data_ptr()
+
+
+class Scan:
+    """One velodyne scan handed out by ScanReader: ``points`` is a float32 [N,4] NumPy view of the
+    pinned host copy (what loadVelodyneData returns, V3:24-28), ``dev_ptr`` its copy in HBM.  Both
+    are only valid until the reader's next scan is fetched; copy ``points`` to keep it."""
+    __slots__ = ("path", "n", "points", "dev_ptr", "_reader", "_ticket")
+
+    def __init__(self, path, n, points, dev_ptr, reader, ticket):
+        self.path, self.n, self.points, self.dev_ptr, self._reader, self._ticket = path, n, points, dev_ptr, reader, ticket
+
+    def _check_live(self):
+        if self._reader._ticket != self._ticket or self._reader._h is None:
+            raise LpfError(-3, "this Scan's buffers were recycled (a later scan has been fetched from its reader)")
+
+
+class ScanReader:
+    """Iterator over velodyne .bin files with read-ahead: a native worker thread reads the next files
+    into pinned memory and copies them to HBM while the current scan is processed (lpf_reader_*).
+    A missing file raises LpfError('<path> does not exist!') for that scan, like V3:26-27."""
+
+    def __init__(self, ctx, paths, n_buffers=3, max_points=1 << 21):
+        self._ctx, self._lib = ctx, ctx._lib
+        self._h = None
+        self._ticket = 0
+        self._paths = [os.fspath(p) for p in paths]
+        self._next_submit = 0
+        self._delivered = 0
+        self._depth = int(n_buffers)
+        h = _P()
+        ctx._check(self._lib.lpf_reader_create(ctx._h, ctypes.byref(h), int(n_buffers), int(max_points)))
+        self._h = h
+        self._top_up()
+
+    def _top_up(self):                         # keep n_buffers - 1 scans ahead of the consumer
+        while self._next_submit < len(self._paths) and self._next_submit - self._delivered < self._depth:
+            self._ctx._check(self._lib.lpf_reader_submit(self._h, self._paths[self._next_submit].encode()))
+            self._next_submit += 1
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self._paths)
+
+    def __next__(self):
+        if self._h is None or self._delivered >= len(self._paths):
+            raise StopIteration
+        path = self._paths[self._delivered]
+        d, hp, n = _P(), _P(), _I64(0)
+        self._ticket += 1
+        rc = self._lib.lpf_reader_next(self._h, ctypes.byref(d), ctypes.byref(hp), ctypes.byref(n))
+        self._delivered += 1
+        self._top_up()
+        self._ctx._check(rc)
+        cnt = int(n.value)
+        if cnt:
+            buf = (ctypes.c_float * (cnt * 4)).from_address(hp.value)
+            pts = np.frombuffer(buf, dtype=np.float32).reshape(cnt, 4)
+        else:
+            pts = np.zeros((0, 4), np.float32)
+        return Scan(path, cnt, pts, d.value, self, self._ticket)
+
+    def wait(self):
+        self._ctx._check(self._lib.lpf_reader_wait(self._h))
+
+    def close(self):
+        if self._h is not None:
+            self._lib.lpf_reader_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LpfContext:
@@ -312,12 +401,21 @@ class LpfContext:
         """frames: list of f32[N_f,4] arrays.  Returns one dict per frame with
         u, v (int32), label_bits, valid_idx, inst_lists, inst_count, count_mb, best_box, best_cnt,
         n_valid, n_labelled (+ depth, uf, vf with want_float)."""
+        scan = frames[0] if (len(frames) == 1 and isinstance(frames[0], Scan)) else None
+        if scan is not None:                     # points already in HBM (ScanReader): no host staging
+            frames = [scan.points]
+        elif any(isinstance(p, Scan) for p in frames):
+            raise ValueError("a Scan from a ScanReader is processed on its own (one frame per run)")
         frames = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 4) for p in frames]
         F = len(frames)
         off = np.zeros(F + 1, np.int64)
         off[1:] = np.cumsum([p.shape[0] for p in frames])
         n = int(off[-1])
         pts = np.concatenate(frames, axis=0) if F > 1 else frames[0]
+        pts_ptr, pts_dev = (pts.ctypes.data if n else None), 0
+        if scan is not None:
+            scan._check_live()
+            pts_ptr, pts_dev = (scan.dev_ptr if n else None), 1
         M = self.M if self.F_masks else 0
         Btot = int(self.box_off[-1]) if self.box_off is not None else 0
         if inst_cap is None:
@@ -338,8 +436,7 @@ class LpfContext:
                               ("valid_idx", vidx), ("inst_idx", iidx), ("count_mb", cmb), ("summary", summ)):
                 setattr(o, name, arr.ctypes.data if arr is not None else None)
             o.inst_cap = inst_cap
-            self._check(self._lib.lpf_run_batch(self._h, pts.ctypes.data if n else None, off.ctypes.data, F, 0,
-                                                ctypes.byref(o)))
+            self._check(self._lib.lpf_run_batch(self._h, pts_ptr, off.ctypes.data, F, pts_dev, ctypes.byref(o)))
             if iidx is not None and summ["inst_overflow"].any():
                 inst_cap = int(summ["inst_off"][:, 32].max())      # exact size now known: run again
                 continue

@@ -990,3 +990,5 @@ int lpf_run(lpf_ctx *c, const float *pts, int64_t N, int pts_on_device, const lp
 }
 
 }  // extern "C"
+
+#include "lpf_reader.hip.h"

@@ -17,7 +17,7 @@ from datetime import datetime
 import numpy as np
 
 from . import kitti360
-from ._native import LpfContext, LPF_MAX_MASKS
+from ._native import LpfContext, LPF_MAX_MASKS, Scan, ScanReader
 
 _CONTEXTS = {}
 
@@ -667,7 +667,7 @@ class FrameInputs:
 
     def __init__(self, frame, points, masks=None, bboxes_3d=None, colors=None, boxes_2d=None):
         self.frame = frame
-        self.points = _f32_points(points).reshape(-1, 4)
+        self.points = points if isinstance(points, Scan) else _f32_points(points).reshape(-1, 4)
         self.masks = masks
         self.bboxes_3d = bboxes_3d if bboxes_3d is not None else []
         n = 0 if masks is None else len(masks)
@@ -708,8 +708,9 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     for f, r, s, pos in zip(frames, res, stacks, positions):
         m = s.shape[0]
         vi = r["valid_idx"]
-        pts_valid = f.points[vi, :3]
-        sets = [f.points[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in r["inst_lists"][:m]]
+        host_pts = f.points.points if isinstance(f.points, Scan) else f.points     # Scan: pinned copy of the file
+        pts_valid = host_pts[vi, :3]
+        sets = [host_pts[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in r["inst_lists"][:m]]
         stats = []
         if f.bboxes_3d and m:
             stats = stats_from_counts(r["inst_count"][:m], r["count_mb"][:m], f.colors, min_points, pos)
@@ -719,6 +720,33 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
                         points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_bits"][vi] != 0,
                         count_mb=r["count_mb"][:m], car_statistics=stats, n_valid=r["n_valid"]))
     return out
+
+
+def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
+                  erode_iters=0, v3_pipeline=False, device=0, n_buffers=3, max_points=None):
+    """The frame loop with read-ahead: scans are read and moved to HBM by the native reader
+    (lpf_reader_*) while earlier frames are processed; yields run_frames' dict per frame.
+    ``inputs_for(i, path)`` returns ``(frame_id, masks, bboxes_3d, colors)`` or None to skip the
+    frame (the reference's ``continue`` rules); it runs while the scan is still being fetched.
+    A missing scan prints the reference's message (cvs_erosion.py:326-330) and is skipped."""
+    scan_paths = [os.fspath(p) for p in scan_paths]
+    if max_points is None:
+        sizes = [os.path.getsize(p) // 16 for p in scan_paths if os.path.isfile(p)]
+        max_points = max(sizes + [1])
+    ctx = get_context(device)
+    with ScanReader(ctx, scan_paths, n_buffers=n_buffers, max_points=max_points) as reader:
+        for i, path in enumerate(scan_paths):
+            inputs = inputs_for(i, path)
+            try:
+                scan = next(reader)
+            except RuntimeError as e:
+                print(f"Failed to load frame {os.path.basename(path)}: {e}")
+                continue
+            if inputs is None:
+                continue
+            frame_id, masks, boxes, colors = inputs
+            yield run_frames([FrameInputs(frame_id, scan, masks, boxes, colors)], TrVeloToRect, camera, depth_max,
+                             min_points, use_oriented, erode_iters, v3_pipeline, device, ctx)[0]
 
 
 # ---------------------------------------------------------------------------------------
@@ -767,15 +795,40 @@ def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, ca
 
 def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None,
                    master_csv_path="results/master_car_statistics.csv", frames=None, batch_frames=32,
-                   erode_iters=0, v3_pipeline=False, device=0, timestamp=None):
+                   erode_iters=0, v3_pipeline=False, device=0, timestamp=None, read_ahead=False):
     """cvs_erosion.process_frames (cvs_erosion.py:298-379): writes the master CSV and prints the
     overall analysis.  ``segmenter(image) -> (img, masks, colors, boxes, confidences)`` is the
     YOLO stage (unchanged subsystem); pass masks it already eroded, or raw masks plus
-    ``erode_iters=1, v3_pipeline=True`` to erode on the GPU."""
+    ``erode_iters=1, v3_pipeline=True`` to erode on the GPU.  ``read_ahead=True`` processes frame
+    by frame with the native scan reader fetching the next files meanwhile (same CSV)."""
     if segmenter is None:
         raise ValueError("process_frames needs the segmentation callable (YOLO stays outside this package)")
     root = kitti360_path or os.environ["KITTI360_DATASET"]
-    _, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    sequence, camera, velo_to_cam, velo_to_rect, velo = sequence_setup(root, seq, cam_id)
+    if read_ahead:
+        todo = velo.available_frames() if frames is None else list(frames)
+        print(f"Found {len(todo)} frames to process")
+
+        def inputs_for(i, path):
+            frame = todo[i]
+            print(f"\nProcessing frame {frame}...")
+            raw = kitti360.load_bounding_boxes(os.path.join(root, "bboxes_3D_cam0", f"BBoxes_{frame}.json"))
+            if not raw:
+                return None
+            image_path = os.path.join(root, "data_2d_raw", sequence, f"image_{cam_id:02d}",
+                                      "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
+            if not os.path.isfile(image_path):
+                return None
+            _, masks, colors, _, _ = segmenter(image_loader(image_path) if image_loader else image_path)
+            if masks is None or len(masks) == 0:
+                return None
+            return frame, masks, prepare_boxes(raw, camera, velo_to_cam), colors
+
+        paths = [os.path.join(velo.raw3DPcdPath, "%010d.bin" % f) for f in todo]
+        for r in stream_frames(paths, inputs_for, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
+            if r["n_valid"] and r["car_statistics"]:
+                append_to_master_csv(r["car_statistics"], r["frame"], master_csv_path, timestamp)
+        return analyze_master_csv(master_csv_path)
     items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames)
     for i in range(0, len(items), batch_frames):
         for r in run_frames(items[i:i + batch_frames], velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):

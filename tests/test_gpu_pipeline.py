@@ -163,6 +163,13 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
     assert got == expect and len(expect) > 5
     text = out.getvalue()
     assert "Found 5 frames to process" in text and "No bounding boxes found" in text and "OVERALL ANALYSIS" in text
+    # the same run frame by frame with the native read-ahead scan reader: same rows, same file
+    csv2 = str(tmp_path / "results2" / "master_car_statistics.csv")
+    with contextlib.redirect_stdout(io.StringIO()) as out2:
+        df2 = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root),
+                                      master_csv_path=csv2, timestamp="T", read_ahead=True)
+    assert open(csv2).read() == open(csv_path).read() and df2.equals(df)
+    assert "Found 5 frames to process" in out2.getvalue() and "OVERALL ANALYSIS" in out2.getvalue()
 
 
 @pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
@@ -292,3 +299,63 @@ def test_first_match_labelling_matches_same_color_loop(calib):
     assert len(set(views["samecolor_mask"].tolist())) > 3 and len(r["car_idx"]) + len(r["background_idx"]) == len(g["valid_idx_d30"])
     empty = pipeline.label_points_first_match(g["points"][:1000], calib["TrVeloToRect"], cam, [], None, depth_max=30)
     assert len(empty["car_idx"]) == 0 and len(empty["background_idx"]) == int(np.sum(g["valid_idx_d30"] < 1000))
+
+
+def test_scan_reader_read_ahead(calib, tmp_path):
+    """lpf_reader_*: files come back in submission order, bit-identical to np.fromfile (V3:24-28), the
+    HBM copy gives the same results as the host path, errors name the file (V3:26-27) and do not stop
+    the reader, and more files than buffers recycle the slots correctly."""
+    from lidar_object_detection_amd._native import LpfError, ScanReader
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    ctx = pipeline.get_context(0)
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    sc = S.scene(50000, n_masks=4, n_boxes=6, seed=5)
+    ctx.set_masks(sc["masks"])
+    ctx.set_boxes(sc["corners_velo"])
+    sizes = [50000, 1, 0, 4096, 33333, 50000, 12345, 8, 40000]
+    paths, clouds = [], []
+    for i, n in enumerate(sizes):
+        pts = S.synthetic_cloud(max(n, 1), seed=100 + i)[:n]
+        p = tmp_path / ("%010d.bin" % i)
+        pts.tofile(p)
+        paths.append(p); clouds.append(pts)
+    bad = tmp_path / "0000000099.bin"
+    bad.write_bytes(b"\x00" * 20)                                   # not a multiple of 16 bytes
+    missing = tmp_path / "0000000098.bin"
+    order = paths[:3] + [missing] + paths[3:6] + [bad] + paths[6:]
+    want = {str(p): c for p, c in zip(paths, clouds)}
+    seen = 0
+    with ScanReader(ctx, order, n_buffers=3, max_points=50000) as rd:
+        assert len(rd) == len(order)
+        it = iter(rd)
+        prev = None
+        for p in order:
+            if p in (missing, bad):
+                with pytest.raises(LpfError) as e:
+                    next(it)
+                assert str(p) in str(e.value) and (("does not exist!" in str(e.value)) == (p == missing))
+                continue
+            scan = next(it)
+            assert scan.path == str(p) and scan.n == len(want[str(p)])
+            assert np.array_equal(scan.points, np.fromfile(p, dtype=np.float32).reshape(-1, 4))
+            r_dev = ctx.run(scan, want_float=True)                  # points taken from the HBM copy
+            r_host = ctx.run(want[str(p)], want_float=True)         # staged from host memory
+            for k in ("u", "v", "label_bits", "valid_idx", "depth", "count_mb", "best_box", "inst_count"):
+                assert np.array_equal(r_dev[k], r_host[k], equal_nan=True), (p, k)
+            for a, b in zip(r_dev["inst_lists"], r_host["inst_lists"]):
+                assert np.array_equal(a, b)
+            if prev is not None:
+                with pytest.raises(LpfError, match="recycled"):
+                    ctx.run(prev)
+            prev = scan
+            seen += 1
+        with pytest.raises(StopIteration):
+            next(it)
+    assert seen == len(paths)
+    with pytest.raises(LpfError, match="at most"):
+        with ScanReader(ctx, [paths[0]], n_buffers=2, max_points=1000) as rd:
+            next(iter(rd))
+    with pytest.raises(LpfError, match="n_buffers"):
+        ScanReader(ctx, [paths[0]], n_buffers=1)
+    ctx.clear_masks(); ctx.clear_boxes()
