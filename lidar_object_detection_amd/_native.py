@@ -68,6 +68,7 @@ def load():
     lib.lpf_set_stream.argtypes = [_P, _P]
     lib.lpf_sync.argtypes = [_P]
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
+    lib.lpf_set_list_kernel.argtypes = [_P, ctypes.c_int]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -97,6 +98,7 @@ def load():
 
 
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
+            "lpf_set_list_kernel",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read",
@@ -249,6 +251,10 @@ class LpfContext:
         """Tail kernels of a device-mode run on a second stream (overlap with the next run); results
         of a run are then complete after sync()."""
         self._check(self._lib.lpf_set_pipelined(self._h, int(bool(on))))
+
+    def set_list_kernel(self, form="auto"):
+        """Form of the list/box-count kernel: "auto" (by launch size), "block" or "wave" per segment; same results."""
+        self._check(self._lib.lpf_set_list_kernel(self._h, {"auto": 0, "block": 1, "wave": 2}[form]))
 
     def graph_begin(self):
         """Start capturing the device-mode calls made on this context into a hipGraph."""

@@ -12,6 +12,12 @@
 #include <string>
 #include <vector>
 
+// Segments below which K2 runs one block (not one wave) per segment.  Measured on MI355X: on real-frame-shaped
+// batches (dense segments) the block form wins at every size tried (30 vs 82 us for 1 frame, 106 vs 127 us for
+// 64 frames = 1728 segments, 210 vs 224 us for 128 frames); on the sparse synthetic bench at 4096 segments the
+// wave form wins (19.8 vs 35.4 us).  The host cannot see the density, so the switch is by size.
+#define LPF_K2_BLOCK_BELOW 2048
+
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_k3_finalize");
 
 namespace {
@@ -70,6 +76,7 @@ struct lpf_ctx {
     } sc[2];
     int parity = 0;
     bool pipelined = false;
+    int list_form = 0;                // lpf_set_list_kernel: 0 by launch size, 1 block per segment, 2 wave per segment
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
@@ -460,6 +467,14 @@ int lpf_sync(lpf_ctx *c)
     return sync_all(c);
 }
 
+int lpf_set_list_kernel(lpf_ctx *c, int form)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (form < 0 || form > 2) return fail(c, LPF_ERR_ARG, "lpf_set_list_kernel: form=%d (0 auto, 1 block per segment, 2 wave per segment)", form);
+    c->list_form = form;
+    return LPF_OK;
+}
+
 int lpf_set_pipelined(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
@@ -758,6 +773,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
         const dim3 g2((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES);
         static const int k2_ablate = getenv("LPF_DEV_K2_ABLATE") ? atoi(getenv("LPF_DEV_K2_ABLATE")) : 0;   // profiling aid only
+        static const int k2_block_below = getenv("LPF_DEV_K2_BLOCK_BELOW") ? atoi(getenv("LPF_DEV_K2_BLOCK_BELOW")) : LPF_K2_BLOCK_BELOW;   // idem
         if (k2_ablate == 4) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         else if (k2_ablate == 8) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         else if (k2_ablate == 2) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
@@ -765,6 +781,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         else if (k2_ablate == 32) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         else if (k2_ablate == 96) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND | LPF_F2_LAB_NOPROJ>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         else if (k2_ablate == 12) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+        else if (c->list_form == 1 || (c->list_form == 0 && nseg_total < k2_block_below))   // four waves per segment (see lpf_k2_block)
+            hipLaunchKernelGGL(lpf_k2_block, dim3(nseg_total), dim3(LPF_BLOCK), 0, tail_stream, P);
         else hipLaunchKernelGGL((lpf_k2_lists), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
         LPF_HIP(c, hipGetLastError());
     }

@@ -20,6 +20,7 @@
 
 #define LPF_BLOCK 256            // 4 waves of 64
 #define LPF_SEG_QUANTUM 4096     // points per segment = 64 ballot rows = one K2 wave; every K1 tile size divides it
+#define LPF_MAX_MASKS_DEV 32     // = LPF_MAX_MASKS of include/lpf.h
 #define LPF_TAB_ROWS 36          // counters per segment: 0 valid, 1 masked, 2+m instance m (34 used)
 #define LPF_TAB_GROUPS 9         // stored as uint4 groups: counter c lives in group c>>2, component c&3
 
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments_t(const LpfParams
 // ------------------------------------------------------------------------------------
 #define LPF_K2_ROWS (LPF_SEG_QUANTUM / 64)
 #define LPF_K2_WAVES 4
+#define LPF_K2_LDSCNT 256         // LDS inside-counters: M * B up to this many (else one global atomic per hit)
 
 __device__ __forceinline__ unsigned lpf_rl(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ float lpf_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz of the current 64 masked points
     __shared__ float4 s_bq[LPF_K2_WAVES][2 * 64];                      // {lo, hi} of the current <= 64 boxes
     __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds
+    __shared__ unsigned s_cnt[LPF_K2_WAVES][LPF_K2_LDSCNT];            // this wave's inside counts [M][B] when they fit
     const int lane = lpf_lane(), wave = lpf_wave();
     const int sid = blockIdx.x * LPF_K2_WAVES + wave;
     if (sid >= P.nseg_total) return;
@@ -566,6 +569,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
     unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    // On a real scan the masked points of a segment sit mostly inside the same one or two boxes: one global
+    // atomic per hit piles thousands of adds onto a handful of L2 addresses (26 us of a 65 us kernel on sample
+    // frame 100).  Counts are gathered per wave in LDS (when M x B fits) and flushed once at the end.
+    const bool lds_cnt = do_box && (P.M * B <= LPF_K2_LDSCNT);
+    if (lds_cnt) {
+        for (int i = lane; i < P.M * B; i += 64) s_cnt[wave][i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
     // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
     // the same order as the set bits of the masked ballots: entry e of the segment, found in
     // row r, is entry e - mbase[first row of r's K1 wave] of that wave.  No gather from the cloud,
@@ -625,7 +636,8 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
                         while (l) {
                             const int m = __ffs(l) - 1;
                             l &= l - 1;
-                            atomicAdd(&cnt[m * B + b], 1u);
+                            if (lds_cnt) atomicAdd(&s_cnt[wave][m * B + b], 1u);
+                            else atomicAdd(&cnt[m * B + b], 1u);
                         }
                     }
                 }
@@ -670,9 +682,243 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (lds_cnt) {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < P.M * B; i += 64) {
+            const unsigned v = s_cnt[wave][i];
+            if (v) atomicAdd(&cnt[i], v);
+        }
+    }
 }
 
 #define lpf_k2_lists lpf_k2_lists_t<0u>
+
+// ------------------------------------------------------------------------------------
+// K2, one BLOCK per segment: same results as lpf_k2_lists_t, for launches that leave most of the chip idle
+// (a single frame, a few real frames).  There a wave has its SIMD to itself and runs at one instruction every
+// ~6 cycles, and real scans are dense in places -- consecutive points are neighbours in space, so a segment
+// lying on cars holds over a thousand valid and hundreds of masked points: the per-segment wave of the
+// throughput form becomes a 40 us serial program (measured on sample frame 100: list building 20 k cycles,
+// 8 chunks x 9 k cycles of instance split + candidate walk + exact test).  Here the four waves of a block share
+// one segment: rows are split four ways for the lists (written row-parallel: a row's valid points go out as
+// one contiguous run, no LDS staging), chunks of 64 masked points are dealt round-robin to the waves, and the
+// order-dependent part -- where in the instance lists a chunk's points go -- comes from a per-(chunk, mask)
+// count table in LDS, so nothing is serial across chunks.
+// ------------------------------------------------------------------------------------
+#define LPF_K2B_LDSB 32           // boxes whose exact parameters the block keeps in LDS
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
+{
+    __shared__ unsigned short s_list[LPF_SEG_QUANTUM];                 // masked points, segment-relative, stable order
+    __shared__ unsigned short s_cc[LPF_K2_ROWS][LPF_MAX_MASKS_DEV];    // [chunk][mask] -> entries of that mask in the chunk
+    __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz + label of a wave's current chunk
+    __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds
+    __shared__ float4 s_bq[2 * 64];                                    // {lo, hi} float bounds of boxes 0..63
+    __shared__ double s_bp[LPF_K2B_LDSB * 16];                         // exact parameters of boxes 0..LPF_K2B_LDSB-1
+    __shared__ unsigned s_cnt[LPF_K2_LDSCNT];                          // inside counts [M][B] when they fit
+    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
+    const int sid = blockIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // ---- round trip 1 (every wave, redundantly: it is 1 KB and the scan is 60 instructions) -------------
+    LpfFrame fr = P.frame0;
+    if (P.F > 1) fr = P.segs[sid];
+    const int ngroups = (2 + P.M + 3) >> 2;
+    unsigned long long vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
+    unsigned long long mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
+    uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < ngroups) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
+    const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
+    const int seg_end = min(seg_start + LPF_SEG_QUANTUM, fr.N);
+    const int nrows = (seg_end - seg_start + 63) >> 6;
+    if (lane >= nrows) { vb = 0; mb = 0; }
+    const unsigned cv = __popcll(vb), cm = __popcll(mb);
+    unsigned iv = cv, im = cm;
+#pragma unroll
+    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {
+        const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
+        if (lane >= o) { iv += tv; im += tm; }
+    }
+    const unsigned vbase = iv - cv, mbase = im - cm;
+    const unsigned L = lpf_rl(im, LPF_K2_ROWS - 1);
+    const long long run_v = (long long)lpf_rl(pre4.x, 0);
+    const int B = fr.B;
+    const bool do_inst = P.inst_idx != nullptr;
+    const bool do_box = (B > 0) && (P.M > 0);
+    const bool masked_part = (L != 0) && (do_inst || do_box);   // block-uniform
+    const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
+    const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
+    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    const bool lds_cnt = do_box && (P.M * B <= LPF_K2_LDSCNT);
+
+    // box data of the frame -> LDS, loads issued before the list work (one round trip for the block)
+    if (masked_part && do_box) {
+        if (tid < 2 * min(B, 64)) s_bq[tid] = boxq[tid];
+        for (int i = tid; i < min(B, LPF_K2B_LDSB) * 16; i += LPF_BLOCK) s_bp[i] = boxp[i];
+        if (lds_cnt) for (int i = tid; i < P.M * B; i += LPF_BLOCK) s_cnt[i] = 0u;
+    }
+    // ---- lists, row-parallel: wave w owns rows 16w .. 16w+15; lane = point of the row -------------------
+    {
+        long long *__restrict__ dst = P.valid_idx ? P.valid_idx + fr.pt_off + run_v : nullptr;
+        for (int r = wave * 16; r < wave * 16 + 16; ++r) {
+            const unsigned long long rv = lpf_rl64(vb, r), rm = lpf_rl64(mb, r);     // wave-uniform
+            if (dst && ((rv >> lane) & 1ull))                                        // contiguous run of popc(rv) entries
+                dst[lpf_rl(vbase, r) + __popcll(rv & lt)] = (long long)(seg_start + r * 64 + lane);
+            if (masked_part && ((rm >> lane) & 1ull))
+                s_list[lpf_rl(mbase, r) + __popcll(rm & lt)] = (unsigned short)(r * 64 + lane);
+        }
+    }
+    if (!masked_part) return;                               // block-uniform: no barrier is skipped by part of a block
+    __syncthreads();
+
+    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;     // K1's hand-off lists (see lpf_k2_lists_t)
+    const int rows_per_wave = P.tile_pts >> 8;
+    const int rpw_shift = (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
+    const int nchunks = (int)((L + 63u) >> 6);
+    auto load_chunk = [&](int c, unsigned &li) -> float4 {  // entry c*64+lane of the segment's masked points (clamped, branch-free)
+        const unsigned e = (unsigned)c * 64u + lane;
+        const bool act = e < L;
+        li = s_list[act ? e : 0];
+        const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
+        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
+        return mseg[act ? first_row * 64 + (int)(e - wb) : 0];
+    };
+    // ---- pass A: per-(chunk, mask) counts; chunks dealt round-robin, the first two kept in registers --------
+    float4 keep_p[2];
+    unsigned keep_li[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { keep_p[k] = make_float4(0.f, 0.f, 0.f, 0.f); keep_li[k] = 0u; }
+    if (do_inst) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = wave + 4 * k;
+            if (c < nchunks) keep_p[k] = load_chunk(c, keep_li[k]);
+        }
+        for (int c = wave, k = 0; c < nchunks; c += 4, ++k) {
+            unsigned li;
+            const float4 p = (k == 0) ? keep_p[0] : (k == 1) ? keep_p[1] : load_chunk(c, li);
+            const unsigned lab = ((unsigned)c * 64u + lane < L) ? __float_as_uint(p.w) : 0u;
+            unsigned mine = 0u;
+            for (int m = 0; m < P.M; ++m) {
+                const unsigned n = (unsigned)__popcll(__ballot((lab >> m) & 1u));
+                if (lane == m) mine = n;
+            }
+            if (lane < LPF_MAX_MASKS_DEV) s_cc[c][lane] = (unsigned short)mine;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B: instance lists + box counts of the wave's chunks ------------------------------------------
+    unsigned *qq = s_q[wave];
+    auto exact = [&](int count) {
+        if (lane < count) {
+            const unsigned ent = qq[lane];
+            const int e = (int)(ent & 63u), b = (int)(ent >> 6);
+            const float4 x = s_pt[wave][e];
+            const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
+            bool in;
+            if (b < LPF_K2B_LDSB) {
+                const double *bp = s_bp + b * 16;
+                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            } else {
+                const double *bp = boxp + (size_t)b * 16;
+                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            }
+            if (in) {
+                unsigned l = __float_as_uint(x.w);
+                while (l) {
+                    const int m = __ffs(l) - 1;
+                    l &= l - 1;
+                    if (lds_cnt) atomicAdd(&s_cnt[m * B + b], 1u);
+                    else atomicAdd(&cnt[m * B + b], 1u);
+                }
+            }
+        }
+    };
+    // lane m: list position of mask m at the start of the segment (the scan already added inst_off[m])
+    unsigned segpos;
+    {
+        const int c = 2 + lane, g = min(c >> 2, LPF_TAB_GROUPS - 1);
+        const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
+        segpos = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
+    }
+    unsigned before = 0u;                                   // lane m: entries of mask m in chunks [0, c) -- advanced incrementally
+    int counted = 0;
+    for (int c = wave, k = 0; c < nchunks; c += 4, ++k) {
+        unsigned li = (k == 0) ? keep_li[0] : keep_li[1];
+        const bool kept = do_inst && k < 2;
+        const float4 p = kept ? ((k == 0) ? keep_p[0] : keep_p[1]) : load_chunk(c, li);
+        const int nact = (int)min(64u, L - (unsigned)c * 64u);
+        const bool act = lane < nact;
+        const unsigned idx = (unsigned)seg_start + li;
+        const unsigned lab = act ? __float_as_uint(p.w) : 0u;
+        if (do_inst) {
+            if (lane < LPF_MAX_MASKS_DEV)
+                for (; counted < c; ++counted) before += s_cc[counted][lane];
+            counted = c;
+            const unsigned posreg = segpos + before;
+            for (int m = 0; m < P.M; ++m) {
+                const bool hit = (lab >> m) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (!bal) continue;
+                const long long base = (long long)lpf_rl(posreg, m);
+                if (hit) {
+                    const long long w = base + __popcll(bal & lt);
+                    if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = (long long)idx;
+                }
+            }
+        }
+        if (!do_box) continue;
+        __builtin_amdgcn_wave_barrier();
+        s_pt[wave][lane] = make_float4(p.x, p.y, p.z, __uint_as_float(lab));   // .w carries the label bits
+        __builtin_amdgcn_wave_barrier();
+        int qn = 0;
+        int cell = 0;
+        if (act) {                                          // same arithmetic as K1 => the same pixel; valid => in range
+            double uf, vf, d;
+            lpf_project_point(P, p.x, p.y, p.z, uf, vf, d);
+            cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
+        }
+        const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
+        for (int w = 0; w < fr.cand_words; ++w) {
+            unsigned long long mset = act ? cg[w] : 0ull;
+            while (__any(mset != 0ull)) {
+                const bool has = mset != 0ull;
+                const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
+                mset &= mset - 1ull;
+                bool near = false;
+                if (has) {
+                    float4 lo, hi;
+                    if (b < 64) { lo = s_bq[2 * b]; hi = s_bq[2 * b + 1]; }
+                    else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
+                    near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
+                }
+                const unsigned long long bal = __ballot(near);
+                if (!bal) continue;
+                if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
+                qn += __popcll(bal);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    exact(64);
+                    const unsigned t = qq[64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    qq[lane] = t;
+                    qn -= 64;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        exact(qn);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lds_cnt) {
+        __syncthreads();
+        for (int i = tid; i < P.M * B; i += LPF_BLOCK) {
+            const unsigned v = s_cnt[i];
+            if (v) atomicAdd(&cnt[i], v);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // K3: one block (4 waves) per frame.  Layout of lpf_frame_summary (include/lpf.h), in

@@ -18,10 +18,12 @@ I32 = np.iinfo(np.int32)
 TOL = 1e-5
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["block", "wave"])
+def ctx(request):
+    """Every parity test runs against both forms of the list/box-count kernel (lpf_set_list_kernel)."""
     from lidar_object_detection_amd._native import LpfContext
     c = LpfContext(0)
+    c.set_list_kernel(request.param)
     yield c
     c.close()
 
