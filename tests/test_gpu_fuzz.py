@@ -1,0 +1,76 @@
+"""Seeded differential fuzz of the whole HIP path against the CPU oracle: random frame counts and sizes, mask
+counts and densities (including full masks -> dense segments), box counts on both sides of the 64-box candidate
+word, oriented / axis-aligned tests, depth windows, and clouds concentrated inside the camera frustum (dense valid
+runs, as real scans have) -- for both forms of the list/box-count kernel."""
+import numpy as np
+import pytest
+
+from lidar_object_detection_amd import synthetic as S
+from oracle import cpu_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _frustum_cloud(rng, n, T, K, W, H, frac_in):
+    """n points, about frac_in of them placed through the inverse projection inside the image (scan-order runs)."""
+    pts = S.synthetic_cloud(max(n, 1), seed=int(rng.integers(1 << 30)))[:n]
+    k = int(n * frac_in)
+    if k:
+        u = np.sort(rng.uniform(-40, W + 40, k))                         # sorted: neighbours in the array are neighbours in the image
+        v = rng.uniform(-20, H + 20, k)
+        d = rng.uniform(0.5, 70.0, k)
+        cam = np.stack([(u - K[0, 2]) * d / K[0, 0], (v - K[1, 2]) * d / K[1, 1], d, np.ones(k)])
+        velo = np.linalg.solve(T, cam)[:3].T
+        start = int(rng.integers(0, n - k + 1))
+        pts[start:start + k, :3] = velo.astype(np.float32)
+    return pts
+
+
+def _case(seed, calib):
+    rng = np.random.default_rng(seed)
+    _, T, K, W, H = S.default_calibration(calib)
+    F = int(rng.integers(1, 5))
+    M = int(rng.choice([0, 1, 3, 8, 9, 17, 32]))
+    oriented = bool(rng.integers(0, 2))
+    dmax = float(rng.choice([30.0, 50.0, 80.0]))
+    frames, masks, boxes = [], [], []
+    for f in range(F):
+        n = int(rng.choice([0, 1, 63, 64, 65, 700, 4096, 4097, 9000, 20000]))
+        frames.append(_frustum_cloud(rng, n, T, K, W, H, float(rng.choice([0.0, 0.3, 0.9]))))
+        m = np.zeros((M, H, W), np.uint8)
+        for i in range(M):
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                m[i] = 1                                                    # full mask: every valid point is masked
+            elif kind == 1:
+                m[i] = (rng.random((H, W)) < 0.5)
+            elif kind == 2:
+                x0, y0 = int(rng.integers(0, W - 50)), int(rng.integers(0, H - 50))
+                m[i, y0:y0 + int(rng.integers(10, 200)), x0:x0 + int(rng.integers(10, 600))] = 1
+        masks.append(m)
+        B = int(rng.choice([0, 1, 7, 33, 64, 65, 130]))
+        boxes.append(S.synthetic_boxes(B, seed=int(rng.integers(1 << 30)))[1] if B else np.zeros((0, 8, 3)))
+    return T, K, W, H, dmax, oriented, M, frames, masks, boxes
+
+
+@pytest.mark.parametrize("form", ["block", "wave"])
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_against_oracle(seed, form, calib):
+    from lidar_object_detection_amd._native import LpfContext
+    T, K, W, H, dmax, oriented, M, frames, masks, boxes = _case(1000 + seed, calib)
+    with LpfContext(0) as ctx:
+        ctx.set_list_kernel(form)
+        ctx.set_camera(T, K, W, H, 0.0, dmax)
+        ctx.set_masks(np.stack(masks))
+        ctx.set_boxes(boxes, oriented=oriented)
+        res = ctx.run_batch(frames, want_float=True)
+    for f, r in enumerate(res):
+        lab = orc.pack_masks(masks[f], 0, H, W) if M else None
+        o = orc.run(frames[f], T, K, W, H, 0.0, dmax, label_img=lab, M=M, corners=boxes[f], oriented=oriented)
+        for k in ("u", "v", "label_bits", "valid_idx", "count_mb", "best_box", "best_cnt", "inst_count"):
+            assert np.array_equal(r[k], o[k]), (seed, form, f, k)
+        assert r["n_valid"] == o["n_valid"]
+        for a, b in zip(r["inst_lists"], o["inst_lists"]):
+            assert np.array_equal(a, b), (seed, form, f)
+        for k in ("depth", "uf", "vf"):
+            assert np.array_equal(r[k], o[k], equal_nan=True), (seed, form, f, k)
