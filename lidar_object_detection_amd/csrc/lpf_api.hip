@@ -621,7 +621,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool host_io = !out->on_device;
     int rc;
 
-    // ---- segmentation: fixed 2048-point segments (K2 blocks); K1 tiles subdivide them ------
+    // ---- segmentation: fixed 4096-point segments (one K2 wave or block each); K1 tiles subdivide them ------
     const int64_t seg_pts = LPF_SEG_QUANTUM;
     if (c->box_F && c->cand_dirty && (rc = build_candidates(c, F))) return rc;
     c->h_frames.resize(F);

@@ -150,9 +150,10 @@ __device__ __forceinline__ void lpf_project_point(const LpfParams &P, float fx, 
 }
 
 // ------------------------------------------------------------------------------------
-// K1: one block = one segment of one frame, streamed in chunks of 2048 points: all eight
-// float4 loads of a lane are issued before the first use, the label gathers of the chunk
-// are issued together, and only then do the ballots / label stores consume them.
+// K1: one block = one tile of 256*ROWS consecutive points of one frame (a segment of 4096 points is 4 or 8
+// tiles); a wave owns ROWS consecutive rows of 64 points.  All float4 loads of a lane are issued before the
+// first use, the label gathers are issued as soon as a row's pixel is known, and only then do the ballots /
+// label stores consume them.
 // Algorithmic HBM bytes per point: 16 (xyzI) + 8 (u,v) + 4 (label) = 28, + 0.25 (ballots).
 // ------------------------------------------------------------------------------------
 // FL bits: production flags first, the LAB_* ones only exist for tools/k1_lab.hip ablations.
