@@ -186,6 +186,9 @@ void lpf_graph_destroy(lpf_graph *g);
  * since the last reset.  (No reference counterpart: the reference has no timers.) */
 int lpf_profile_enable(lpf_ctx *ctx, int on);
 int lpf_profile_read(lpf_ctx *ctx, double *k1_ms_sum, int64_t *k1_launches, int reset);
+/* Duration between two event records with nothing between them on the context's stream (median of 33):
+ * the part of an lpf_profile_* bracket that is not the kernel (4.6 us on MI355X / ROCm 7.2). */
+int lpf_profile_overhead(lpf_ctx *ctx, double *empty_bracket_ms);
 
 /* ---- scan reader ------------------------------------------------------------------------------
  * Double-buffered velodyne .bin reader for frame loops and the 10 Hz stream.  Stands where the

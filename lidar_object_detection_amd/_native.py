@@ -87,6 +87,7 @@ def load():
     lib.lpf_graph_destroy.restype = None
     lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
     lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
+    lib.lpf_profile_overhead.argtypes = [_P, ctypes.POINTER(ctypes.c_double)]
     lib.lpf_reader_create.argtypes = [_P, ctypes.POINTER(_P), ctypes.c_int, _I64]
     lib.lpf_reader_submit.argtypes = [_P, ctypes.c_char_p]
     lib.lpf_reader_next.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I64)]
@@ -101,7 +102,7 @@ EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "l
             "lpf_set_list_kernel",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
             "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
 
@@ -280,6 +281,12 @@ class LpfContext:
         ms, n = ctypes.c_double(0.0), _I64(0)
         self._check(self._lib.lpf_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
         return ms.value, int(n.value)
+
+    def profile_overhead(self):
+        """Milliseconds between two event records with nothing in between (what a bracket adds to a kernel)."""
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.lpf_profile_overhead(self._h, ctypes.byref(ms)))
+        return ms.value
 
     # -- state ------------------------------------------------------------------------
     def set_camera(self, T_velo_to_rect, K, width, height, depth_min=0.0, depth_max=50.0):
