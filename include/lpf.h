@@ -206,6 +206,7 @@ int lpf_profile_overhead(lpf_ctx *ctx, double *empty_bracket_ms);
  *                      on the context's stream may still use them after that).  A missing / malformed
  *                      file gives LPF_ERR_IO for that scan (lpf_last_error names it) and the reader
  *                      carries on with the following one.
+ *   lpf_reader_destroy before lpf_destroy of its context (the reader uses the context's stream).
  *   lpf_reader_wait    host-side wait for the copy of the scan handed out last (only for callers that
  *                      touch *d_pts outside the context's stream). */
 typedef struct lpf_reader lpf_reader;

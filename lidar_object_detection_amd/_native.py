@@ -6,6 +6,7 @@ tensors are passed by ``data_ptr()`` in device mode.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -152,6 +153,7 @@ class ScanReader:
         h = _P()
         ctx._check(self._lib.lpf_reader_create(ctx._h, ctypes.byref(h), int(n_buffers), int(max_points)))
         self._h = h
+        ctx._readers.add(self)                  # the context closes its readers before it goes away
         self._top_up()
 
     def _top_up(self):                         # keep n_buffers - 1 scans ahead of the consumer
@@ -214,6 +216,7 @@ class LpfContext:
         if rc != 0:
             raise LpfError(rc, (self._lib.lpf_last_error(None) or b"").decode())
         self._h = h
+        self._readers = weakref.WeakSet()
         self.device = int(device)
         self.W = self.H = 0
         self.M = 0
@@ -227,6 +230,8 @@ class LpfContext:
 
     def close(self):
         if getattr(self, "_h", None):
+            for r in list(getattr(self, "_readers", ())):      # a reader holds pointers into its context
+                r.close()
             self._lib.lpf_destroy(self._h)
             self._h = None
 
