@@ -93,7 +93,7 @@ int  lpf_sync(lpf_ctx *ctx);
  * complete after lpf_sync(), not after the caller's stream alone.  Off by default. */
 int  lpf_set_pipelined(lpf_ctx *ctx, int on);
 /* The list/box-count kernel exists in two forms with identical results: one wave per 4096-point segment
- * (fewest instructions; right for big sparse batches that fill the chip) and one block of four waves per
+ * (fewest instructions; right for big sparse batches that fill the chip) and one block of four or eight waves per
  * segment (right for a single frame or a batch of real frames, whose segments on cars hold hundreds of
  * masked points).  0 = choose by launch size (default), 1 = block per segment, 2 = wave per segment. */
 int  lpf_set_list_kernel(lpf_ctx *ctx, int form);

@@ -700,20 +700,21 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
 // ~6 cycles, and real scans are dense in places -- consecutive points are neighbours in space, so a segment
 // lying on cars holds over a thousand valid and hundreds of masked points: the per-segment wave of the
 // throughput form becomes a 40 us serial program (measured on sample frame 100: list building 20 k cycles,
-// 8 chunks x 9 k cycles of instance split + candidate walk + exact test).  Here the four waves of a block share
-// one segment: rows are split four ways for the lists (written row-parallel: a row's valid points go out as
+// 8 chunks x 9 k cycles of instance split + candidate walk + exact test).  Here the NW (4 or 8) waves of a block share
+// one segment: rows are split NW ways for the lists (written row-parallel: a row's valid points go out as
 // one contiguous run, no LDS staging), chunks of 64 masked points are dealt round-robin to the waves, and the
 // order-dependent part -- where in the instance lists a chunk's points go -- comes from a per-(chunk, mask)
 // count table in LDS, so nothing is serial across chunks.
 // ------------------------------------------------------------------------------------
 #define LPF_K2B_LDSB 32           // boxes whose exact parameters the block keeps in LDS
 
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
+template <int NW>   // waves per segment: 4 or 8
+__global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
 {
     __shared__ unsigned short s_list[LPF_SEG_QUANTUM];                 // masked points, segment-relative, stable order
     __shared__ unsigned short s_cc[LPF_K2_ROWS][LPF_MAX_MASKS_DEV];    // [chunk][mask] -> entries of that mask in the chunk
-    __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz + label of a wave's current chunk
-    __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds
+    __shared__ float4 s_pt[NW][64];                          // xyz + label of a wave's current chunk
+    __shared__ unsigned s_q[NW][128];                        // (point, box) pairs that passed the float bounds
     __shared__ float4 s_bq[2 * 64];                                    // {lo, hi} float bounds of boxes 0..63
     __shared__ double s_bp[LPF_K2B_LDSB * 16];                         // exact parameters of boxes 0..LPF_K2B_LDSB-1
     __shared__ unsigned s_cnt[LPF_K2_LDSCNT];                          // inside counts [M][B] when they fit
@@ -754,13 +755,13 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
     // box data of the frame -> LDS, loads issued before the list work (one round trip for the block)
     if (masked_part && do_box) {
         if (tid < 2 * min(B, 64)) s_bq[tid] = boxq[tid];
-        for (int i = tid; i < min(B, LPF_K2B_LDSB) * 16; i += LPF_BLOCK) s_bp[i] = boxp[i];
-        if (lds_cnt) for (int i = tid; i < P.M * B; i += LPF_BLOCK) s_cnt[i] = 0u;
+        for (int i = tid; i < min(B, LPF_K2B_LDSB) * 16; i += NW * 64) s_bp[i] = boxp[i];
+        if (lds_cnt) for (int i = tid; i < P.M * B; i += NW * 64) s_cnt[i] = 0u;
     }
-    // ---- lists, row-parallel: wave w owns rows 16w .. 16w+15; lane = point of the row -------------------
+    // ---- lists, row-parallel: wave w owns 64/NW consecutive rows; lane = point of the row ---------------
     {
         long long *__restrict__ dst = P.valid_idx ? P.valid_idx + fr.pt_off + run_v : nullptr;
-        for (int r = wave * 16; r < wave * 16 + 16; ++r) {
+        for (int r = wave * (64 / NW); r < (wave + 1) * (64 / NW); ++r) {
             const unsigned long long rv = lpf_rl64(vb, r), rm = lpf_rl64(mb, r);     // wave-uniform
             if (dst && ((rv >> lane) & 1ull))                                        // contiguous run of popc(rv) entries
                 dst[lpf_rl(vbase, r) + __popcll(rv & lt)] = (long long)(seg_start + r * 64 + lane);
@@ -791,10 +792,10 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
     if (do_inst) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int c = wave + 4 * k;
+            const int c = wave + NW * k;
             if (c < nchunks) keep_p[k] = load_chunk(c, keep_li[k]);
         }
-        for (int c = wave, k = 0; c < nchunks; c += 4, ++k) {
+        for (int c = wave, k = 0; c < nchunks; c += NW, ++k) {
             unsigned li;
             const float4 p = (k == 0) ? keep_p[0] : (k == 1) ? keep_p[1] : load_chunk(c, li);
             const unsigned lab = ((unsigned)c * 64u + lane < L) ? __float_as_uint(p.w) : 0u;
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
     }
     unsigned before = 0u;                                   // lane m: entries of mask m in chunks [0, c) -- advanced incrementally
     int counted = 0;
-    for (int c = wave, k = 0; c < nchunks; c += 4, ++k) {
+    for (int c = wave, k = 0; c < nchunks; c += NW, ++k) {
         unsigned li = (k == 0) ? keep_li[0] : keep_li[1];
         const bool kept = do_inst && k < 2;
         const float4 p = kept ? ((k == 0) ? keep_p[0] : keep_p[1]) : load_chunk(c, li);
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_block(const LpfParams P)
     }
     if (lds_cnt) {
         __syncthreads();
-        for (int i = tid; i < P.M * B; i += LPF_BLOCK) {
+        for (int i = tid; i < P.M * B; i += NW * 64) {
             const unsigned v = s_cnt[i];
             if (v) atomicAdd(&cnt[i], v);
         }
