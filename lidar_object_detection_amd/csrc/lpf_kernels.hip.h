@@ -76,6 +76,8 @@ struct LpfParams {
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
                                  // bits} of its masked points in point order (K2 never gathers from the cloud)
     int tile_pts;                // points per K1 tile of this launch (4 waves)
+    int inline_scan;             // 1: no scan kernel ran -- lpf_k2_block derives its prefixes from seg_tab, lpf_k3_finalize the
+                                 // totals (and cleans seg_tab); only when every frame has <= 64 segments
 };
 
 __device__ __forceinline__ int lpf_lane() { return threadIdx.x & 63; }
@@ -694,6 +696,29 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
 
 #define lpf_k2_lists lpf_k2_lists_t<0u>
 
+// Small frames (<= 64 segments, lane = segment) need no scan kernel: a wave derives, from the frame's rows of
+// seg_tab, for counter c = lane: bef = sum over the frame's segments before segment k, tot = sum over all of them.
+__device__ __forceinline__ void lpf_wave_frame_counts(const LpfParams &P, const LpfFrame &fr, int k, int lane, unsigned &bef, unsigned &tot)
+{
+    const int ngroups = (2 + P.M + 3) >> 2;
+    bef = 0u; tot = 0u;
+    for (int g = 0; g < ngroups; ++g) {
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < fr.nseg) t = P.seg_tab[(size_t)g * P.nseg_cap + fr.seg_off + lane];
+        unsigned x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {              // inclusive scan over the segments
+                const unsigned u = __shfl_up(x[j], o);
+                if (lane >= o) x[j] += u;
+            }
+            const unsigned b = (k > 0) ? lpf_rl(x[j], k - 1) : 0u, a = lpf_rl(x[j], 63);
+            if (lane == 4 * g + j) { bef = b; tot = a; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // K2, one BLOCK per segment: same results as lpf_k2_lists_t, for launches that leave most of the chip idle
 // (a single frame, a few real frames).  There a wave has its SIMD to itself and runs at one instruction every
@@ -728,7 +753,7 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
     unsigned long long vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
     unsigned long long mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
     uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < ngroups) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
+    if (lane < ngroups && !P.inline_scan) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
     const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
     const int seg_end = min(seg_start + LPF_SEG_QUANTUM, fr.N);
     const int nrows = (seg_end - seg_start + 63) >> 6;
@@ -742,7 +767,21 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
     }
     const unsigned vbase = iv - cv, mbase = im - cm;
     const unsigned L = lpf_rl(im, LPF_K2_ROWS - 1);
-    const long long run_v = (long long)lpf_rl(pre4.x, 0);
+    long long run_v = (long long)lpf_rl(pre4.x, 0);
+    unsigned segpos_inline = 0u;                            // lane m: list position of mask m at the start of the segment
+    if (P.inline_scan) {
+        unsigned bef, tot;
+        lpf_wave_frame_counts(P, fr, sid - fr.seg_off, lane, bef, tot);
+        run_v = (long long)lpf_rl(bef, 0);
+        unsigned off = (lane >= 2 && lane < 2 + P.M) ? tot : 0u;     // inst_off[m] = totals of the masks before m
+        const unsigned own = off;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(off, o);
+            if (lane >= o) off += u;
+        }
+        segpos_inline = (unsigned)__shfl((int)(off - own + bef), (lane + 2) & 63);
+    }
     const int B = fr.B;
     const bool do_inst = P.inst_idx != nullptr;
     const bool do_box = (B > 0) && (P.M > 0);
@@ -842,6 +881,7 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
         const int c = 2 + lane, g = min(c >> 2, LPF_TAB_GROUPS - 1);
         const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
         segpos = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
+        if (P.inline_scan) segpos = segpos_inline;
     }
     unsigned before = 0u;                                   // lane m: entries of mask m in chunks [0, c) -- advanced incrementally
     int counted = 0;
@@ -937,7 +977,20 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
     char *base = P.summary ? (char *)P.summary + (size_t)f * LPF_SUMMARY_BYTES : nullptr;
     long long *w = (long long *)base;
     int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
+    __shared__ unsigned s_tot[LPF_TAB_ROWS];
     const unsigned *__restrict__ tot = P.frame_tot + (size_t)f * LPF_TAB_ROWS;
+    if (P.inline_scan) {                                    // block-uniform: the frame's totals, then seg_tab is handed back clean
+        if (tid < 64) {
+            unsigned bef, all;
+            lpf_wave_frame_counts(P, fr, 0, lane, bef, all);
+            if (lane < LPF_TAB_ROWS) s_tot[lane] = (lane < 2 + M) ? all : 0u;
+        }
+        __syncthreads();
+        tot = s_tot;
+        const int ngroups = (2 + M + 3) >> 2;
+        for (int i = tid; i < ngroups * fr.nseg; i += LPF_BLOCK)
+            P.seg_tab[(size_t)(i / fr.nseg) * P.nseg_cap + fr.seg_off + (i % fr.nseg)] = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
