@@ -52,14 +52,37 @@ def pmc_traffic(points_per_launch):
     return None
 
 
-def cpu_baseline(scene, T, K, W, H, budget_s):
-    """Reference NumPy statements (oracle/numpy_path.py) on this host, bounded sample."""
-    from oracle import numpy_path as npp
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
     try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        blas_threads = 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(scene, T, K, W, H, budget_s):
+    """Reference NumPy statements (oracle/numpy_path.py) on this host, bounded sample, BLAS threads = usable CPUs."""
+    from oracle import numpy_path as npp
+    cpus = usable_cpus()
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cpus)             # more threads than the quota allows only get the process throttled
+    except Exception:
+        cpus = 1
     n = len(scene["points"])
     reps, t0 = 0, time.perf_counter()
     while True:
@@ -68,9 +91,12 @@ def cpu_baseline(scene, T, K, W, H, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or reps >= 50:
             break
-    out = {"value": n * reps / el, "unit": "points/s", "cores": int(blas_threads), "kind": "port",
+    if limiter is not None:
+        limiter.restore_original_limits()
+    out = {"value": n * reps / el, "unit": "points/s", "cores": int(cpus), "kind": "port",
            "sample": "%d x the same %d-point cloud (%d masks, %d boxes), NumPy %s statements of V3:565-592/211-233/344-379 "
-                     "(oracle/numpy_path.py), os.cpu_count()=%d" % (reps, n, N_MASKS, N_BOXES, np.__version__, os.cpu_count())}
+                     "(oracle/numpy_path.py), BLAS threads = usable CPUs = %d (os.cpu_count()=%d)"
+                     % (reps, n, N_MASKS, N_BOXES, np.__version__, cpus, os.cpu_count())}
     # the single-thread C restatement beside it
     from oracle import cpu_oracle as orc
     lab = orc.pack_masks(scene["masks"], 0, H, W)
