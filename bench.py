@@ -107,6 +107,19 @@ def cpu_baseline(scene, T, K, W, H, budget_s):
                 want_float=False)
         r2 += 1
     out["c_oracle_1thread_points_per_s"] = n * r2 / (time.perf_counter() - t0)
+    # ... and on every usable CPU at once: clouds are independent units, one C call per thread (ctypes drops the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def work(_):
+        for _i in range(4):
+            orc.run(scene["points"], T, K, W, H, 0.0, DMAX, label_img=lab, M=N_MASKS, corners=scene["corners_velo"],
+                    want_float=False, inst_stride=max(n // 8, 1))
+        return 4
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cpus) as pool:
+        done = sum(pool.map(work, range(cpus)))
+    out["c_oracle_allcpus_points_per_s"] = n * done / (time.perf_counter() - t0)
+    out["c_oracle_threads"] = cpus
     return out
 
 
