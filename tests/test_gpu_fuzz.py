@@ -2,6 +2,8 @@
 counts and densities (including full masks -> dense segments), box counts on both sides of the 64-box candidate
 word, oriented / axis-aligned tests, depth windows, and clouds concentrated inside the camera frustum (dense valid
 runs, as real scans have) -- for both forms of the list/box-count kernel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,7 +56,7 @@ def _case(seed, calib):
 
 
 @pytest.mark.parametrize("form", ["block", "wave"])
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24"))))
 def test_fuzz_against_oracle(seed, form, calib):
     from lidar_object_detection_amd._native import LpfContext
     T, K, W, H, dmax, oriented, M, frames, masks, boxes = _case(1000 + seed, calib)
