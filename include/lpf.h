@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 1
+#define LPF_ABI_VERSION 2          /* 2: lpf_outputs gained uv_valid / label_valid */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -75,8 +75,11 @@ typedef struct lpf_outputs {
     int32_t  *count_mb;    /* [M * Btot] frame f's [M][B_f] block at M*box_off[f]:
                                           np.sum(oriented_point_in_bbox(car_points_m, box_b)), V3:366-370 */
     lpf_frame_summary *summary;  /* [F] */
-    int32_t   on_device;   /* 1: all pointers above are device pointers, call is asynchronous */
+    int32_t   on_device;   /* 1: all pointers in this struct are device pointers, call is asynchronous */
     int32_t   reserved;
+    int32_t  *uv_valid;    /* [Ntot][2]  compact: u_valid, v_valid = u[valid], v[valid] (V3:590-591) -- frame f's at
+                              uv_valid[frame_off[f] ...], in valid_idx order, n_valid entries.  Needs valid_idx too. */
+    uint32_t *label_valid; /* [Ntot]     compact: label_bits[valid_indices], same order */
 } lpf_outputs;
 
 /* ---- lifetime ---------------------------------------------------------------- */

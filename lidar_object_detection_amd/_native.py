@@ -41,7 +41,8 @@ assert SUMMARY_DTYPE.itemsize == ctypes.sizeof(FrameSummary) == 928
 class Outputs(ctypes.Structure):
     _fields_ = [("uv", _P), ("label_bits", _P), ("depth", _P), ("u_f", _P), ("v_f", _P),
                 ("valid_idx", _P), ("inst_idx", _P), ("inst_cap", _I64), ("count_mb", _P),
-                ("summary", _P), ("on_device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("summary", _P), ("on_device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("uv_valid", _P), ("label_valid", _P)]
 
 
 _lib = None
@@ -415,10 +416,11 @@ class LpfContext:
         return self.run_batch([points], **kw)[0]
 
     def run_batch(self, frames, want_uv=True, want_label=True, want_float=False, want_lists=True,
-                  inst_cap=None):
+                  inst_cap=None, want_valid_uv=False):
         """frames: list of f32[N_f,4] arrays.  Returns one dict per frame with
         u, v (int32), label_bits, valid_idx, inst_lists, inst_count, count_mb, best_box, best_cnt,
-        n_valid, n_labelled (+ depth, uf, vf with want_float)."""
+        n_valid, n_labelled (+ depth, uf, vf with want_float; + u_valid, v_valid, label_valid with
+        want_valid_uv: the values at the valid points only -- with want_uv/want_label off, a quarter of the read-back)."""
         scan = frames[0] if (len(frames) == 1 and isinstance(frames[0], Scan)) else None
         if scan is not None:                     # points already in HBM (ScanReader): no host staging
             frames = [scan.points]
@@ -447,11 +449,14 @@ class LpfContext:
             uf = np.empty(n, np.float64) if want_float else None
             vf = np.empty(n, np.float64) if want_float else None
             vidx = np.empty(n, np.int64) if want_lists else None
+            uvv = np.empty((n, 2), np.int32) if (want_valid_uv and want_lists) else None     # only the first n_valid rows come back
+            labv = np.empty(n, np.uint32) if (want_valid_uv and want_lists) else None
             iidx = np.empty((F, inst_cap), np.int64) if (want_lists and M) else None
             cmb = np.zeros(max(M * Btot, 1), np.int32)
             summ = np.zeros(F, SUMMARY_DTYPE)
             for name, arr in (("uv", uv), ("label_bits", lab), ("depth", dep), ("u_f", uf), ("v_f", vf),
-                              ("valid_idx", vidx), ("inst_idx", iidx), ("count_mb", cmb), ("summary", summ)):
+                              ("valid_idx", vidx), ("inst_idx", iidx), ("count_mb", cmb), ("summary", summ),
+                              ("uv_valid", uvv), ("label_valid", labv)):
                 setattr(o, name, arr.ctypes.data if arr is not None else None)
             o.inst_cap = inst_cap
             self._check(self._lib.lpf_run_batch(self._h, pts_ptr, off.ctypes.data, F, pts_dev, ctypes.byref(o)))
@@ -474,6 +479,9 @@ class LpfContext:
                 r["depth"], r["uf"], r["vf"] = dep[a:b], uf[a:b], vf[a:b]
             if want_lists:
                 r["valid_idx"] = vidx[a:a + r["n_valid"]]
+                if uvv is not None:
+                    r["u_valid"], r["v_valid"] = uvv[a:a + r["n_valid"], 0], uvv[a:a + r["n_valid"], 1]
+                    r["label_valid"] = labv[a:a + r["n_valid"]]
                 r["inst_lists"] = [iidx[f, int(s["inst_off"][m]):int(s["inst_off"][m + 1])] for m in range(M)] \
                     if iidx is not None else []
             if self.box_off is not None:
@@ -486,7 +494,7 @@ class LpfContext:
 
     # -- the hot path, device tensors (asynchronous) -------------------------------------
     def run_device(self, pts, frame_off, uv=None, label_bits=None, depth=None, u_f=None, v_f=None,
-                   valid_idx=None, inst_idx=None, inst_cap=0, count_mb=None, summary=None):
+                   valid_idx=None, inst_idx=None, inst_cap=0, count_mb=None, summary=None, uv_valid=None, label_valid=None):
         """Enqueue one batch on the context's stream.  pts: torch float32 [Ntot,4] on the GPU;
         outputs: preallocated torch tensors (None = not wanted); summary: uint8 [F*928].
         frame_off: int64 NumPy/sequence [F+1] (host)."""
@@ -502,6 +510,7 @@ class LpfContext:
         o.inst_cap = int(inst_cap)
         o.count_mb = _dev_ptr(count_mb, "int32")
         o.summary = _dev_ptr(summary)
+        o.uv_valid, o.label_valid = _dev_ptr(uv_valid, "int32"), _dev_ptr(label_valid)
         self._check(self._lib.lpf_run_batch(self._h, _dev_ptr(pts, "float32"), off.ctypes.data, F, 1,
                                             ctypes.byref(o)))
 
@@ -521,6 +530,7 @@ class LpfContext:
         o.inst_cap = int(outs.get("inst_cap", 0))
         o.count_mb = _dev_ptr(outs.get("count_mb"), "int32")
         o.summary = _dev_ptr(outs.get("summary"))
+        o.uv_valid, o.label_valid = _dev_ptr(outs.get("uv_valid"), "int32"), _dev_ptr(outs.get("label_valid"))
         lib, h, check = self._lib, self._h, self._check
         p_pts, p_off, p_out = _P(_dev_ptr(pts, "float32")), _P(off.ctypes.data), ctypes.byref(o)
         run, setm = lib.lpf_run_batch, lib.lpf_set_masks_u8

@@ -82,6 +82,7 @@ struct lpf_ctx {
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out, boxprep, dimg;
+    DevBuf st_uvv, st_labv;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
     std::vector<LpfFrame> h_segs;
@@ -436,7 +437,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -693,8 +694,15 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             P.field = (decltype(P.field))out->member;                             \
         }                                                                         \
     }
+    if ((out->uv_valid || out->label_valid) && !out->valid_idx)
+        return fail(c, LPF_ERR_ARG, "run: uv_valid / label_valid need valid_idx as well (they share its order)");
     LPF_OUTBUF(uv, uv, st_uv, n * 8)
     LPF_OUTBUF(label_bits, label_bits, st_label, n * 4)
+    // the compact copies are gathered from the dense arrays: keep those in internal buffers when the caller skips them
+    if (out->uv_valid && !P.uv) { if ((rc = reserve(c, c->st_uv, n * 8))) return rc; P.uv = (decltype(P.uv))c->st_uv.p; }
+    if (out->label_valid && !P.label_bits) { if ((rc = reserve(c, c->st_label, n * 4))) return rc; P.label_bits = (decltype(P.label_bits))c->st_label.p; }
+    LPF_OUTBUF(uv_valid, uv_valid, st_uvv, n * 8)
+    LPF_OUTBUF(label_valid, label_valid, st_labv, n * 4)
     LPF_OUTBUF(depth, depth, st_depth, n * 8)
     LPF_OUTBUF(uf, u_f, st_uf, n * 8)
     LPF_OUTBUF(vf, v_f, st_vf, n * 8)
@@ -823,6 +831,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             const size_t nv = (size_t)hs[f].n_valid;
             if (out->valid_idx && nv)
                 LPF_HIP(c, hipMemcpyAsync(out->valid_idx + frame_off[f], P.valid_idx + frame_off[f], nv * 8,
+                                          hipMemcpyDeviceToHost, c->stream));
+            if (out->uv_valid && nv)
+                LPF_HIP(c, hipMemcpyAsync(out->uv_valid + 2 * frame_off[f], P.uv_valid + frame_off[f], nv * 8,
+                                          hipMemcpyDeviceToHost, c->stream));
+            if (out->label_valid && nv)
+                LPF_HIP(c, hipMemcpyAsync(out->label_valid + frame_off[f], P.label_valid + frame_off[f], nv * 4,
                                           hipMemcpyDeviceToHost, c->stream));
             int64_t tot = hs[f].inst_off[LPF_MAX_MASKS];
             if (tot > out->inst_cap) tot = out->inst_cap;

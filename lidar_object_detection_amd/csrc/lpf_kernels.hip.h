@@ -63,6 +63,8 @@ struct LpfParams {
     uint32_t *label_bits;
     double *depth, *uf, *vf;
     long long *valid_idx;
+    int2 *uv_valid;              // compact (u, v) / labels of the valid points, in valid_idx order (needs uv / label_bits)
+    uint32_t *label_valid;
     long long *inst_idx;
     int32_t *count_out;
     void *summary;               // lpf_frame_summary[F]
@@ -551,6 +553,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
         __builtin_amdgcn_wave_barrier();
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
         for (unsigned e = lane; e < nv; e += 64) dst[e] = (long long)(seg_start + (int)lst[e]);
+        if (P.uv_valid || P.label_valid) {                 // compact copies for callers that only read the valid points
+            const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+            for (unsigned e = lane; e < nv; e += 64) {
+                const long long g = g0 + (int)lst[e];
+                if (P.uv_valid) P.uv_valid[o + e] = P.uv[g];
+                if (P.label_valid) P.label_valid[o + e] = P.label_bits[g];
+            }
+        }
         __builtin_amdgcn_wave_barrier();                   // the list is reused for the masked points
     }
     const int B = fr.B;
@@ -802,8 +812,12 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
         long long *__restrict__ dst = P.valid_idx ? P.valid_idx + fr.pt_off + run_v : nullptr;
         for (int r = wave * (64 / NW); r < (wave + 1) * (64 / NW); ++r) {
             const unsigned long long rv = lpf_rl64(vb, r), rm = lpf_rl64(mb, r);     // wave-uniform
-            if (dst && ((rv >> lane) & 1ull))                                        // contiguous run of popc(rv) entries
-                dst[lpf_rl(vbase, r) + __popcll(rv & lt)] = (long long)(seg_start + r * 64 + lane);
+            if (dst && ((rv >> lane) & 1ull)) {                                      // contiguous run of popc(rv) entries
+                const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt), g = fr.pt_off + seg_start + r * 64 + lane;
+                dst[pos] = (long long)(seg_start + r * 64 + lane);
+                if (P.uv_valid) P.uv_valid[fr.pt_off + run_v + pos] = P.uv[g];
+                if (P.label_valid) P.label_valid[fr.pt_off + run_v + pos] = P.label_bits[g];
+            }
             if (masked_part && ((rm >> lane) & 1ull))
                 s_list[lpf_rl(mbase, r) + __popcll(rm & lt)] = (unsigned short)(r * 64 + lane);
         }

@@ -691,10 +691,14 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     if M > LPF_MAX_MASKS:
         raise NotImplementedError("more than %d detections in one frame" % LPF_MAX_MASKS)
     is_f = any(s.dtype == np.float32 for s in stacks if s.shape[0])
-    batch = np.zeros((len(frames), M, H, W), np.float32 if is_f else np.uint8)
-    for i, s in enumerate(stacks):
-        if s.shape[0]:
-            batch[i, :s.shape[0]] = s
+    dt = np.float32 if is_f else np.uint8
+    if all(s.shape[0] == M and s.dtype == dt for s in stacks):          # the usual case: no padding, no extra copy
+        batch = stacks[0][None] if len(stacks) == 1 else np.stack(stacks)
+    else:                                                               # ragged detection counts: pad with empty masks
+        batch = np.zeros((len(frames), M, H, W), dt)
+        for i, s in enumerate(stacks):
+            if s.shape[0]:
+                batch[i, :s.shape[0]] = s
     corners, positions = [], []
     for f in frames:
         c, pos = _corners_velo(f.bboxes_3d)
@@ -703,7 +707,8 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
     ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline)
     ctx.set_boxes(corners, oriented=use_oriented)
-    res = ctx.run_batch([f.points for f in frames])
+    # only the valid points' pixels and labels are used below: fetch those (a quarter of the dense arrays on real frames)
+    res = ctx.run_batch([f.points for f in frames], want_uv=False, want_label=False, want_valid_uv=True)
     out = []
     for f, r, s, pos in zip(frames, res, stacks, positions):
         m = s.shape[0]
@@ -716,8 +721,8 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
             stats = stats_from_counts(r["inst_count"][:m], r["count_mb"][:m], f.colors, min_points, pos)
             for d in stats:
                 d.pop("_best_col"), d.pop("_best_count")
-        out.append(dict(frame=f.frame, valid_indices=vi, u_valid=r["u"][vi].astype(np.int64), v_valid=r["v"][vi].astype(np.int64),
-                        points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_bits"][vi] != 0,
+        out.append(dict(frame=f.frame, valid_indices=vi, u_valid=r["u_valid"].astype(np.int64), v_valid=r["v_valid"].astype(np.int64),
+                        points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_valid"] != 0,
                         count_mb=r["count_mb"][:m], car_statistics=stats, n_valid=r["n_valid"]))
     return out
 

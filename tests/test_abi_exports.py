@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_native.EXPORTED) == names
     lib.lpf_abi_version.restype = ctypes.c_int
-    assert lib.lpf_abi_version() == 1
+    assert lib.lpf_abi_version() == 2
 
 
 def test_struct_mirrors():
     assert ctypes.sizeof(_native.FrameSummary) == 928 == _native.SUMMARY_DTYPE.itemsize
     assert _native.FrameSummary.inst_off.offset == 8 * 34 and _native.FrameSummary.best_box.offset == 8 * 99
-    assert ctypes.sizeof(_native.Outputs) == 11 * 8
+    assert ctypes.sizeof(_native.Outputs) == 13 * 8 and _native.Outputs.uv_valid.offset == 11 * 8
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

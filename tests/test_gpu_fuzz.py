@@ -65,13 +65,15 @@ def test_fuzz_against_oracle(seed, form, calib):
         ctx.set_camera(T, K, W, H, 0.0, dmax)
         ctx.set_masks(np.stack(masks))
         ctx.set_boxes(boxes, oriented=oriented)
-        res = ctx.run_batch(frames, want_float=True)
+        res = ctx.run_batch(frames, want_float=True, want_valid_uv=True)
     for f, r in enumerate(res):
         lab = orc.pack_masks(masks[f], 0, H, W) if M else None
         o = orc.run(frames[f], T, K, W, H, 0.0, dmax, label_img=lab, M=M, corners=boxes[f], oriented=oriented)
         for k in ("u", "v", "label_bits", "valid_idx", "count_mb", "best_box", "best_cnt", "inst_count"):
             assert np.array_equal(r[k], o[k]), (seed, form, f, k)
         assert r["n_valid"] == o["n_valid"]
+        assert np.array_equal(r["u_valid"], o["u"][o["valid_idx"]]) and np.array_equal(r["v_valid"], o["v"][o["valid_idx"]])
+        assert np.array_equal(r["label_valid"], o["label_bits"][o["valid_idx"]])
         for a, b in zip(r["inst_lists"], o["inst_lists"]):
             assert np.array_equal(a, b), (seed, form, f)
         for k in ("depth", "uf", "vf"):

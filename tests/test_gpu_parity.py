@@ -220,11 +220,18 @@ def test_batch_equals_single_frames(ctx, calib):
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     ctx.set_masks(masks)
     ctx.set_boxes([sc["corners_velo"] for sc in scenes])
-    rs = ctx.run_batch(frames, want_float=True)
+    rs = ctx.run_batch(frames, want_float=True, want_valid_uv=True)
+    lean = ctx.run_batch(frames, want_uv=False, want_label=False, want_valid_uv=True)     # dense arrays not requested
     for f, (sc, p) in enumerate(zip(scenes, frames)):
         lab = orc.pack_masks(sc["masks"], 0, H, W)
         o = orc.run(p, T, K, W, H, 0.0, 30.0, label_img=lab, M=4, corners=sc["corners_velo"])
         _compare(rs[f], o, 4)
+        for r in (rs[f], lean[f]):                          # compact outputs == u[valid], v[valid], labels[valid] (V3:590-591)
+            vi = o["valid_idx"]
+            assert np.array_equal(r["valid_idx"], vi)
+            assert np.array_equal(r["u_valid"], o["u"][vi]) and np.array_equal(r["v_valid"], o["v"][vi])
+            assert np.array_equal(r["label_valid"], o["label_bits"][vi])
+        assert "u" not in lean[f] and "label_bits" not in lean[f]
 
 
 def test_inst_capacity_overflow_is_reported_and_recovered(ctx, calib):
@@ -456,6 +463,11 @@ def test_error_codes_are_loud(calib):
     c.clear_boxes()
     r = c.run(pts)                                                           # and it still works afterwards
     assert r["n_valid"] == orc.run(pts, T, K, W, H, 0.0, 50.0, want_float=False)["n_valid"]
+    with pytest.raises(LpfError, match="need valid_idx"):
+        from lidar_object_detection_amd._native import Outputs
+        import ctypes
+        o2 = Outputs(); buf = np.empty((1000, 2), np.int32); o2.uv_valid = buf.ctypes.data
+        c._check(c._lib.lpf_run(c._h, pts.ctypes.data, 1000, 0, ctypes.byref(o2)))
     with pytest.raises(LpfError, match="inst_cap"):
         from lidar_object_detection_amd._native import Outputs
         import ctypes
