@@ -359,3 +359,29 @@ def test_scan_reader_read_ahead(calib, tmp_path):
     with pytest.raises(LpfError, match="n_buffers"):
         ScanReader(ctx, [paths[0]], n_buffers=1)
     ctx.clear_masks(); ctx.clear_boxes()
+
+
+def test_integration_md_ctypes_stub_runs(calib):
+    """The raw ctypes stub printed in INTEGRATION.md section C is executed as written (frame 100, 5 masks, 25 boxes)
+    and its results compared with the golden vectors: the document cannot drift from the ABI."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## C. Raw ctypes stub"):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    code = code.replace('ctypes.CDLL("lidar_object_detection_amd/liblpf.so")',
+                        'ctypes.CDLL(%r)' % os.path.join(root, "lidar_object_detection_amd", "liblpf.so"))
+    g = load_golden(100)
+    cam = _camera(calib)
+    ns = {"TrVeloToRect": calib["TrVeloToRect"], "camera": cam, "points": np.ascontiguousarray(g["points"]),
+          "masks": unpack_masks(g, "rect5", cam.height, cam.width), "m_": 2,
+          "bboxes_3d": [{"corners_velo": c.tolist()} for c in g["corners_velo"]]}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    assert np.array_equal(ns["valid_indices"], g["valid_idx_d50"])
+    M, B = 5, len(g["corners_velo"])
+    assert np.array_equal(ns["cnt"].reshape(M, B), g["count_mb_rect5_d50"])
+    off = np.concatenate([[0], np.cumsum(g["inst_count_rect5_d50"])])
+    want = g["points"][g["inst_cat_rect5_d50"][off[2]:off[3]], :3]
+    assert np.array_equal(ns["car_points_m"], want) and len(want) > 0
+    assert np.array_equal(ns["uv"][:, 0], np.clip(g["u"], I32.min, I32.max))
+    ns["lib"].lpf_destroy(ns["ctx"])
