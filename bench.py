@@ -52,19 +52,20 @@ def pmc_traffic(points_per_launch):
     return None
 
 
-def usable_cpus():
-    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+def usable_cpus(cgroup_root="/sys/fs/cgroup"):
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one
+    (cgroup v2 ``cpu.max`` = "<quota|max> <period>", v1 ``cpu/cpu.cfs_quota_us`` + ``cpu.cfs_period_us``)."""
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 1
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+    for path in (os.path.join(cgroup_root, "cpu.max"), os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")):
         try:
             txt = open(path).read().split()
             if path.endswith("cpu.max"):
                 quota, period = txt[0], float(txt[1])
             else:
-                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota, period = txt[0], float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
             if quota not in ("max", "-1"):
                 n = max(1, min(n, int(float(quota) / period + 0.5)))
             break

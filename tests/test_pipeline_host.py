@@ -225,3 +225,20 @@ def test_firsttest_iou_match_threshold_matches_reference(views, calib):
         assert len(pairs) == m1 - m0
         for (c, col), wc, wcol in zip(pairs, views["first_match_corners"][m0:m1], views["first_match_color"][m0:m1]):
             assert np.array_equal(c, wc) and np.array_equal(col, wcol)
+
+
+def test_bench_usable_cpus_reads_cgroup_quota(tmp_path):
+    """bench.py sizes the CPU baseline's thread pool by what the container may use (cgroup v2 and v1 formats)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    aff = len(os.sched_getaffinity(0))
+    (tmp_path / "v2").mkdir(); (tmp_path / "v2" / "cpu.max").write_text("300000 100000\n")
+    assert bench.usable_cpus(str(tmp_path / "v2")) == min(aff, 3)
+    (tmp_path / "v2max").mkdir(); (tmp_path / "v2max" / "cpu.max").write_text("max 100000\n")
+    assert bench.usable_cpus(str(tmp_path / "v2max")) == aff
+    (tmp_path / "v1" / "cpu").mkdir(parents=True)
+    (tmp_path / "v1" / "cpu" / "cpu.cfs_quota_us").write_text("200000\n"); (tmp_path / "v1" / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.usable_cpus(str(tmp_path / "v1")) == min(aff, 2)
+    (tmp_path / "none").mkdir()
+    assert bench.usable_cpus(str(tmp_path / "none")) == aff
