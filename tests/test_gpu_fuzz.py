@@ -59,7 +59,7 @@ def _case(seed, calib):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24"))))
 def test_fuzz_against_oracle(seed, form, calib):
     from lidar_object_detection_amd._native import LpfContext
-    T, K, W, H, dmax, oriented, M, frames, masks, boxes = _case(1000 + seed, calib)
+    T, K, W, H, dmax, oriented, M, frames, masks, boxes = _case(int(os.environ.get("LPF_FUZZ_SEED_BASE", "1000")) + seed, calib)
     with LpfContext(0) as ctx:
         ctx.set_list_kernel(form)
         ctx.set_camera(T, K, W, H, 0.0, dmax)
