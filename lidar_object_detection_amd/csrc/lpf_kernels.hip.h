@@ -171,16 +171,15 @@ __device__ __forceinline__ void lpf_project_point(const LpfParams &P, float fx, 
 #define LPF_F_LAB_NOBAL 64u
 #define LPF_F_LAB_NOTAB 128u
 
-template <int ROWS, unsigned FL, typename LT = uint32_t>   // LT: label-image element (uint8 for M <= 8, uint16 for M <= 16)
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
+template <int ROWS, unsigned FL, typename LT>
+__device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, unsigned *s_cnt)
 {
     // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
-    __shared__ unsigned s_cnt[LPF_TAB_ROWS];
     constexpr int TILE = LPF_BLOCK * ROWS;
     static_assert(LPF_SEG_QUANTUM % TILE == 0, "tiles must divide segments");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const int tiles_per_seg = P.seg_pts / TILE;
-    const int lb = lpf_xcd_remap(blockIdx.x, P.nseg_total * tiles_per_seg);
+    const int lb = lpf_xcd_remap(blk, P.nseg_total * tiles_per_seg);
     const int sid = lb / tiles_per_seg;
     LpfFrame fr = P.frame0;
     if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];        // wave-uniform: scalar loads, no search
@@ -297,6 +296,13 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
                 atomicAdd(reinterpret_cast<unsigned long long *>(P.seg_tab + (size_t)(tid >> 1) * P.nseg_cap + sid) + (tid & 1), v);
         }
     }
+}
+
+template <int ROWS, unsigned FL, typename LT = uint32_t>   // LT: label-image element (uint8 for M <= 8, uint16 for M <= 16)
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
+{
+    __shared__ unsigned s_cnt[LPF_TAB_ROWS];
+    lpf_k1_tile<ROWS, FL, LT>(P, (int)blockIdx.x, s_cnt);
 }
 
 #define LPF_K1_FLAGS (LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE)
