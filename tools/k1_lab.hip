@@ -55,32 +55,35 @@ static void launch_t(const LpfParams &P, int nblk, hipStream_t s)
 }
 
 // The same tiles handed out through an atomic work counter to a resident grid -- the skeleton of a work-queue kernel
-// that could take tail work items behind the tiles.  Measured at 16 M points: 200-230 us against
-// 85 us for the plain grid launch (index fetch latency per tile exposed, XCD locality of the label image lost).
+// that could take tail work items behind the tiles.  Measured at 16 M points against 84 us for the
+// plain grid launch: 211 us with one tile per pop (a single address absorbs an atomic every ~13 ns), 108 / 111 / 138 us with
+// 4 / 8 / 16 tiles per pop.  usage: k1_lab N NBUF ITERS [resident blocks] [tiles per pop]
 template <int ROWS, unsigned FL, typename LT = uint32_t>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_persist_t(const LpfParams P, unsigned *queue, int ntiles)
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_persist_t(const LpfParams P, unsigned *queue, int ntiles, int grab)
 {
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
     __shared__ int s_next;
     for (;;) {
-        if (threadIdx.x == 0) s_next = (int)atomicAdd(queue, 1u);
+        if (threadIdx.x == 0) s_next = (int)atomicAdd(queue, (unsigned)grab);     // `grab` consecutive tiles per pop
         __syncthreads();
-        const int t = s_next;
-        if (t >= ntiles) break;                             // block-uniform; every block reaches it
-        lpf_k1_tile<ROWS, FL, LT>(P, t, s_cnt);
-        __syncthreads();
+        const int t0 = s_next;
+        if (t0 >= ntiles) break;                            // block-uniform; every block reaches it
+        for (int t = t0; t < min(t0 + grab, ntiles); ++t) {
+            lpf_k1_tile<ROWS, FL, LT>(P, t, s_cnt);
+            __syncthreads();
+        }
     }
 }
 
 // work-queue form of the same kernel: a resident grid of `g_persist_blocks` blocks pops tiles from an atomic counter
 static unsigned *g_queue = nullptr;
-static int g_persist_blocks = 256 * 7;
+static int g_persist_blocks = 256 * 7, g_grab = 1;
 template <int ROWS, unsigned FL>
 static void launch_persist_t(const LpfParams &P, int nblk, hipStream_t s)
 {
     const int ntiles = nblk * (P.seg_pts / (LPF_BLOCK * ROWS));
     (void)hipMemsetAsync(g_queue, 0, 4, s);
-    hipLaunchKernelGGL((lpf_k1_persist_t<ROWS, FL>), dim3(g_persist_blocks), dim3(LPF_BLOCK), 0, s, P, g_queue, ntiles);
+    hipLaunchKernelGGL((lpf_k1_persist_t<ROWS, FL>), dim3(g_persist_blocks), dim3(LPF_BLOCK), 0, s, P, g_queue, ntiles, g_grab);
 }
 
 int main(int argc, char **argv)
@@ -125,6 +128,7 @@ int main(int argc, char **argv)
     };
     CK(hipMalloc(&g_queue, 4));
     if (argc > 4) g_persist_blocks = atoi(argv[4]);
+    if (argc > 5) g_grab = atoi(argv[5]);
     {   // reference kernels
         float4 *o4; CK(hipMalloc(&o4, (size_t)N * 16));
         auto timeit = [&](const char *name, auto fn, double bytes) {
