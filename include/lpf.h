@@ -193,6 +193,15 @@ int lpf_profile_read(lpf_ctx *ctx, double *k1_ms_sum, int64_t *k1_launches, int 
  * the part of an lpf_profile_* bracket that is not the kernel (4.6 us on MI355X / ROCm 7.2). */
 int lpf_profile_overhead(lpf_ctx *ctx, double *empty_bracket_ms);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------------------------
+ * Frames shard across ranks with no data-path collective (V3:541: the frame loop has no cross-frame state);
+ * what the ranks exchange at the end is a short int64 vector -- the aggregates of analyze_master_csv
+ * (cvs:268-295): frames with rows, cars, matched cars, sums of total / inside / outside points, the inside
+ * percentages as integer hundredths -- summed (op 0), or reduced by MIN (1) / MAX (2).  vec: host memory,
+ * reduced in place over the caller's RCCL communicator (ncclComm_t, from ncclCommInitRank), one rank per GPU,
+ * on the context's stream; returns when vec holds the result.  librccl is loaded at the first call. */
+int lpf_allreduce_metrics(lpf_ctx *ctx, int64_t *vec, int n, int op, void *rccl_comm);
+
 /* ---- scan reader ------------------------------------------------------------------------------
  * Double-buffered velodyne .bin reader for frame loops and the 10 Hz stream.  Stands where the
  * reference calls Kitti360Viewer3DRaw.loadVelodyneData once per frame (V3:24-28, V3:545:

@@ -15,7 +15,7 @@ ARCH = "gfx950"
 
 # -ffp-contract=off: the kernels spell out every fma() the reference's BLAS performs;
 # the compiler must not fuse (or split) anything else, or integer outputs can flip.
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ldl",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

@@ -71,6 +71,7 @@ def load():
     lib.lpf_sync.argtypes = [_P]
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
     lib.lpf_set_list_kernel.argtypes = [_P, ctypes.c_int]
+    lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -101,7 +102,7 @@ def load():
 
 
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
-            "lpf_set_list_kernel",
+            "lpf_set_list_kernel", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
@@ -262,6 +263,14 @@ class LpfContext:
     def set_list_kernel(self, form="auto"):
         """Form of the list/box-count kernel: "auto" (by launch size), "block" or "wave" per segment; same results."""
         self._check(self._lib.lpf_set_list_kernel(self._h, {"auto": 0, "block": 1, "wave": 2}[form]))
+
+    def allreduce_metrics(self, vec, rccl_comm, op="sum"):
+        """In-place all-reduce of an int64 NumPy vector over an RCCL communicator (an ncclComm_t as an integer /
+        c_void_p, e.g. from ncclCommInitRank through ctypes); op: "sum", "min" or "max"."""
+        a = np.ascontiguousarray(vec, dtype=np.int64)
+        self._check(self._lib.lpf_allreduce_metrics(self._h, a.ctypes.data, int(a.size), {"sum": 0, "min": 1, "max": 2}[op],
+                                                    rccl_comm if isinstance(rccl_comm, ctypes.c_void_p) else _P(rccl_comm)))
+        return a
 
     def graph_begin(self):
         """Start capturing the device-mode calls made on this context into a hipGraph."""

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -1007,6 +1008,39 @@ int lpf_profile_enable(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
     c->profiling = on != 0;
+    return LPF_OK;
+}
+
+// ---- the one exchange step of the sharded path: a small int64 all-reduce over RCCL -----------------------
+// librccl is resolved at the first call (dlopen), so liblpf.so carries no link-time dependency on it and a
+// single-GPU user never loads it.  The communicator is the caller's (ncclCommInitRank / ncclCommInitAll).
+int lpf_allreduce_metrics(lpf_ctx *c, int64_t *vec, int n, int op, void *rccl_comm)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!vec || n <= 0 || n > (1 << 20) || op < 0 || op > 2 || !rccl_comm)
+        return fail(c, LPF_ERR_ARG, "allreduce_metrics: vec=%p n=%d op=%d (0 sum, 1 min, 2 max) comm=%p", (void *)vec, n, op, rccl_comm);
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_allreduce_metrics inside graph capture");
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef const char *(*errstr_fn)(int);
+    static allreduce_fn p_allreduce = nullptr;
+    static errstr_fn p_errstr = nullptr;
+    if (!p_allreduce) {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail(c, LPF_ERR_STATE, "allreduce_metrics: cannot load librccl.so (%s)", dlerror());
+        p_allreduce = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        p_errstr = (errstr_fn)dlsym(h, "ncclGetErrorString");
+        if (!p_allreduce) return fail(c, LPF_ERR_STATE, "allreduce_metrics: librccl.so has no ncclAllReduce");
+    }
+    int rc;
+    if ((rc = reserve(c, c->pib_out, (size_t)n * 8))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(c->pib_out.p, vec, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    static const int red[3] = {0 /* ncclSum */, 3 /* ncclMin */, 2 /* ncclMax */};
+    const int nrc = p_allreduce(c->pib_out.p, c->pib_out.p, (size_t)n, 4 /* ncclInt64 */, red[op], rccl_comm, c->stream);
+    if (nrc != 0) return fail(c, LPF_ERR_HIP, "ncclAllReduce failed: %s", p_errstr ? p_errstr(nrc) : "?");
+    LPF_HIP(c, hipMemcpyAsync(vec, c->pib_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));
     return LPF_OK;
 }
 

@@ -49,8 +49,17 @@ def _tensor(arr, device):
     return torch.as_tensor(np.asarray(arr, dtype=np.int64), device=device)
 
 
-def allreduce_aggregates(vec, lo, hi, device="cpu", group=None):
-    """SUM / MIN / MAX over all ranks; returns NumPy values every rank can read."""
+def allreduce_aggregates(vec, lo, hi, device="cpu", group=None, ctx=None, rccl_comm=None):
+    """SUM / MIN / MAX over all ranks; returns NumPy values every rank can read.  By default through
+    torch.distributed (backend "nccl" = RCCL on ROCm); a host that is not a torch program passes its own
+    communicator and the context instead and the C ABI does the exchange (lpf_allreduce_metrics)."""
+    if rccl_comm is not None:
+        if ctx is None:
+            raise ValueError("allreduce over a raw RCCL communicator needs the LpfContext of this rank")
+        out = ctx.allreduce_metrics(np.asarray(vec, np.int64).copy(), rccl_comm, "sum")
+        lo_r = ctx.allreduce_metrics(np.array([lo], np.int64), rccl_comm, "min")
+        hi_r = ctx.allreduce_metrics(np.array([hi], np.int64), rccl_comm, "max")
+        return out, int(lo_r[0]), int(hi_r[0])
     import torch.distributed as dist
     t = _tensor(vec, device)
     tlo, thi = _tensor([lo], device), _tensor([hi], device)

@@ -407,3 +407,38 @@ def test_integration_md_python_snippets_run(calib, tmp_path, monkeypatch):
     assert np.array_equal(ns["valid_indices"], g["valid_idx_d50"]) and np.array_equal(ns["u_valid"], g["u"][g["valid_idx_d50"]])
     assert [d["points_inside_bbox"] for d in ns["car_statistics"]] == g["stats_points_inside_bbox_rect5_d50"].tolist()
     assert os.path.isfile(tmp_path / "results" / "master_car_statistics.csv")
+
+
+def test_allreduce_metrics_over_rccl_single_rank():
+    """lpf_allreduce_metrics with a real RCCL communicator (one rank = this GPU; the N-rank case is the same call):
+    sum / min / max of an int64 vector come back unchanged, argument errors are reported."""
+    import ctypes
+    from lidar_object_detection_amd._native import LpfContext, LpfError
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1"):
+        try:
+            rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl.so not found")
+    comm = ctypes.c_void_p()
+    dev = (ctypes.c_int * 1)(0)
+    rccl.ncclCommInitAll.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, dev) == 0
+    try:
+        with LpfContext(0) as ctx:
+            vec = np.array([3, 25, 21, 8833, 8274, 559, 7000, 412345], np.int64)     # the 8-word aggregate of distributed.py
+            for op in ("sum", "min", "max"):
+                got = ctx.allreduce_metrics(vec.copy(), comm, op)
+                assert np.array_equal(got, vec), op
+            big = np.arange(-5000, 5000, dtype=np.int64) * (1 << 40)
+            assert np.array_equal(ctx.allreduce_metrics(big.copy(), comm), big)
+            with pytest.raises(LpfError, match="allreduce_metrics"):
+                ctx.allreduce_metrics(np.zeros(0, np.int64), comm)
+            with pytest.raises(LpfError, match="comm"):
+                ctx.allreduce_metrics(vec.copy(), ctypes.c_void_p(None))
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
