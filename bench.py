@@ -16,11 +16,20 @@ kernel (-> roofline).  Rank 0 prints ONE JSON line.
 
 Multi-GPU: frames/clouds are independent units, so ranks shard them with no data-path
 collective (weak scaling); the only exchange is one RCCL all-reduce of the aggregate
-counters at the end of the timed region.
+counters at the end of the timed region.  `python bench.py --gpus N` without a launcher
+starts its own N ranks (a parent that never touches the GPU spawns torch.distributed.run).
+
+With N = 1 the line also carries `secondary`: the other BASELINE.json configs measured in
+the same process, each checked against the CPU oracle / the committed golden vectors --
+configs[2] literally (one 2 M-point cloud per launch), configs[3]'s shape (20 real frames in
+one batch) and configs[4] (10 Hz-style stream, hipGraph per frame, p50 latency).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,19 +46,38 @@ ALGO_BYTES_PER_POINT = 28          # 16 B xyzI read + 8 B (u,v) write + 4 B labe
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+PMC_FILE = "r02_pmc_bench_f8x2M.json"
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the kernel sources: a committed counter pass only describes the kernels it ran."""
+    h = hashlib.sha256()
+    for name in ("lpf_kernels.hip.h", "lpf_api.hip"):
+        with open(os.path.join(ROOT, "lidar_object_detection_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(points_per_launch):
-    """HBM bytes per launch of the project+label kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as tools/pmc_summary.py documents), or
-    None when no committed pass matches this launch size."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_f8x2M.json")
-    if points_per_launch != 8 * 2_000_000 or not os.path.exists(path):
-        return None
+    """(HBM bytes per launch of the project+label kernel, provenance note).  The bytes come from the committed
+    rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as tools/pmc_summary.py documents) and
+    are only reported when those passes ran THIS source (sha of csrc/ recorded beside them) at this launch size;
+    otherwise None -- a stale figure is worse than none."""
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.exists(path):
+        return None, "no committed counter pass (profiles/%s)" % PMC_FILE
     with open(path) as f:
         d = json.load(f)
+    meta = d.get("_meta", {})
+    if meta.get("points_per_launch") != points_per_launch:
+        return None, "profiles/%s was collected at %s points per launch" % (PMC_FILE, meta.get("points_per_launch"))
+    if meta.get("kernel_source_sha16") != kernel_source_sha():
+        return None, "profiles/%s was collected on kernel sources %s, these are %s: re-run tools/refresh_profiles.sh" % (
+            PMC_FILE, meta.get("kernel_source_sha16"), kernel_source_sha())
     for k, v in d.items():
         if "lpf_k1_project_t" in k:
-            return v["hbm_bytes_per_launch"]
-    return None
+            return v["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, kernel sources %s)" % (PMC_FILE, kernel_source_sha())
+    return None, "profiles/%s has no entry for the project+label kernel" % PMC_FILE
 
 
 def usable_cpus(cgroup_root="/sys/fs/cgroup"):
@@ -124,6 +152,202 @@ def cpu_baseline(scene, T, K, W, H, budget_s):
     return out
 
 
+# How a step's kernels are queued (name -> tail overlaps next step, pack on a side stream, CUs of the side streams, text)
+MODES = {
+    "serial": (False, False, 0, "every kernel of a step on one stream, in order"),
+    "pipeline": (True, False, 0, "tail kernels (scan, lists, finalize) of step i on a second stream, overlapping step i+1"),
+    "pipeline-pack": (True, True, 0, "pipeline + the mask pack of step i+1 on a third stream"),
+    "partition": (True, True, 32, "pipeline-pack with both side streams confined to 32 CUs (4 per XCD)"),
+}
+DEFAULT_MODE = "serial"
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: this parent makes no GPU call; it starts the N ranks
+    as a child `python -m torch.distributed.run ... bench.py <same arguments>` and leaves with the child's exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def make_outputs(torch, dev, ntot, F, inst_cap_total, M, Btot, summary_bytes):
+    return dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev),
+                label_bits=torch.empty(ntot, dtype=torch.int32, device=dev),
+                valid_idx=torch.empty(ntot, dtype=torch.int64, device=dev),
+                inst_idx=torch.empty(inst_cap_total, dtype=torch.int64, device=dev),
+                count_mb=torch.zeros(max(M * Btot, 1), dtype=torch.int32, device=dev),
+                summary=torch.zeros(F * summary_bytes, dtype=torch.uint8, device=dev))
+
+
+def time_steps(torch, dev, fns, steps, warmup, sync):
+    for i in range(warmup):
+        fns[i % len(fns)]()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fns[i % len(fns)]()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_lines(torch, dev, local_rank, T, K, W, H):
+    """The other BASELINE.json configs on this GPU, same process, each checked before it is timed."""
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    from oracle import cpu_oracle as orc
+    out = {}
+    stream = torch.cuda.Stream(dev)
+
+    def sync():
+        stream.synchronize()
+
+    # ---- configs[2] literally: ONE synthetic 2 M-point cloud + 8 masks + 32 boxes per launch set ------------------
+    with torch.cuda.stream(stream), LpfContext(local_rank) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_camera(T, K, W, H, 0.0, DMAX)
+        n = N_POINTS
+        scs = [S.scene(n, N_MASKS, N_BOXES, seed=7000 + i) for i in range(6)]     # 6 x 56 MB of traffic: past the 256 MiB cache
+        ctx.set_boxes(scs[0]["corners_velo"])
+        bufs = []
+        for sc in scs:
+            o = make_outputs(torch, dev, n, 1, n, N_MASKS, N_BOXES, SUMMARY_DTYPE.itemsize)
+            bufs.append((torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev), o))
+        off = np.array([0, n], np.int64)
+        fns = [ctx.make_device_step(p_, off, masks_u8=m_, inst_cap=n, **o) for p_, m_, o in bufs]
+        sync()
+        fns[0]()
+        sync()
+        o = bufs[0][2]
+        ref = orc.run(scs[0]["points"], T, K, W, H, 0.0, DMAX, label_img=orc.pack_masks(scs[0]["masks"], 0, H, W), M=N_MASKS,
+                      corners=scs[0]["corners_velo"], want_float=False)
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
+        ok = (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(o["valid_idx"][:ref["n_valid"]].cpu().numpy(), ref["valid_idx"])
+              and np.array_equal(o["count_mb"].cpu().numpy().reshape(N_MASKS, N_BOXES), ref["count_mb"])
+              and np.array_equal(o["uv"].cpu().numpy(), np.stack([ref["u"], ref["v"]], axis=1))
+              and np.array_equal(o["label_bits"].cpu().numpy().view(np.uint32), ref["label_bits"]))
+        if not ok:
+            raise SystemExit("bench secondary configs[2]: GPU result differs from the CPU oracle")
+        dt = time_steps(torch, dev, fns, 300, 30, sync)
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        time_steps(torch, dev, fns, 100, 0, sync)
+        ms, cnt = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        k1_us = 1e3 * ms / max(cnt, 1)
+        out["configs2_one_2M_cloud_per_launch"] = {
+            "points_per_s": n / dt, "us_per_step": 1e6 * dt, "k1_bracket_us": k1_us,
+            "k1_algorithmic_GBps": ALGO_BYTES_PER_POINT * n / (k1_us * 1e-6) / 1e9,
+            "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * n / dt / 1e9 / HBM_PEAK_GBS,
+            "checked": "n_valid, valid_idx, u, v, label_bits, count_mb == CPU oracle"}
+        del bufs, fns
+
+    # ---- configs[3] shape: the 20 sample frames' worth of REAL scan data in one batch (golden frame 100 x 20) -------
+    gpath = os.path.join(ROOT, "tests", "golden", "frame_0000000100.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        cal = np.load(os.path.join(ROOT, "tests", "golden", "calib_cam0.npz"))
+        Tg, Kg, Wg, Hg = np.asarray(cal["TrVeloToRect"]), np.asarray(cal["K"])[:3, :3], int(cal["width"]), int(cal["height"])
+        pts = np.ascontiguousarray(g["points"])
+        masks = np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :Wg].astype(np.uint8)
+        corners = g["corners_velo"]
+        n, M, B, F = len(pts), len(masks), len(corners), 20
+        with torch.cuda.stream(stream), LpfContext(local_rank) as ctx:
+            ctx.set_stream(stream.cuda_stream)
+            ctx.set_camera(Tg, Kg, Wg, Hg, 0.0, 50.0)
+            ctx.set_boxes([corners] * F)
+            d_pts = torch.from_numpy(np.tile(pts, (F, 1))).to(dev)
+            d_masks = torch.from_numpy(np.tile(masks[None], (F, 1, 1, 1))).to(dev)
+            o = make_outputs(torch, dev, F * n, F, F * n, M, F * B, SUMMARY_DTYPE.itemsize)
+            fn = ctx.make_device_step(d_pts, np.arange(F + 1, dtype=np.int64) * n, masks_u8=d_masks, inst_cap=n, **o)
+            sync()
+            fn()
+            sync()
+            cm = o["count_mb"].cpu().numpy().reshape(F, M, B)
+            sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+            vi = o["valid_idx"].cpu().numpy()
+            ok = all(np.array_equal(cm[f], g["count_mb_rect5_d50"]) and int(sm[f]["n_valid"]) == len(g["valid_idx_d50"])
+                     and np.array_equal(vi[f * n:f * n + len(g["valid_idx_d50"])], g["valid_idx_d50"]) for f in range(F))
+            if not ok:
+                raise SystemExit("bench secondary configs[3]: GPU result differs from the golden vectors of frame 100")
+            dt = time_steps(torch, dev, [fn], 500, 30, sync)
+            out["configs3_20_real_frames_one_batch"] = {
+                "points_per_s": F * n / dt, "us_per_step": 1e6 * dt, "frames": F, "points_per_frame": n, "masks": M, "boxes": B,
+                "checked": "count_mb, n_valid, valid_idx of every frame == tests/golden/frame_0000000100.npz (reference functions)"}
+            # ... and the same frame alone (configs[1]): launch-bound
+            o1 = make_outputs(torch, dev, n, 1, n, M, B, SUMMARY_DTYPE.itemsize)
+            ctx.set_boxes(corners)
+            fn1 = ctx.make_device_step(d_pts[:n], np.array([0, n], np.int64), masks_u8=d_masks[:1], inst_cap=n, **o1)
+            fn1()
+            sync()
+            if not np.array_equal(o1["count_mb"].cpu().numpy().reshape(M, B), g["count_mb_rect5_d50"]):
+                raise SystemExit("bench secondary configs[1]: GPU result differs from the golden vectors of frame 100")
+            dt1 = time_steps(torch, dev, [fn1], 1000, 30, sync)
+            out["configs1_frame100_device_resident"] = {"points_per_s": n / dt1, "us_per_frame": 1e6 * dt1, "points": n,
+                                                        "checked": "count_mb == golden"}
+
+    # ---- configs[4]: stream of 1 M-point frames + 8 masks eroded once, H2D + kernels + D2H in one hipGraph per frame ----
+    n, M, B = 1_000_000, 8, 32
+    scs = [S.scene(n, M, B, seed=1000 + i) for i in range(4)]
+    h_pts = torch.empty((n, 4), dtype=torch.float32).pin_memory()
+    h_masks = torch.empty((1, M, H, W), dtype=torch.uint8).pin_memory()
+    h_sum = torch.empty(SUMMARY_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.empty(M * B, dtype=torch.int32).pin_memory()
+    with torch.cuda.stream(stream), LpfContext(local_rank) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_camera(T, K, W, H, 0.0, 50.0)
+        ctx.set_boxes(scs[0]["corners_velo"])
+        d_pts = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        d_masks = torch.empty((1, M, H, W), dtype=torch.uint8, device=dev)
+        o = make_outputs(torch, dev, n, 1, n, M, B, SUMMARY_DTYPE.itemsize)
+        step = ctx.make_device_step(d_pts, np.array([0, n], np.int64), masks_u8=d_masks, erode_iters=1, inst_cap=n, **o)
+
+        def frame_work():
+            d_pts.copy_(h_pts, non_blocking=True)
+            d_masks.copy_(h_masks, non_blocking=True)
+            step()
+            h_sum.copy_(o["summary"], non_blocking=True)
+            h_cnt.copy_(o["count_mb"], non_blocking=True)
+
+        h_pts.copy_(torch.from_numpy(scs[0]["points"]))
+        h_masks.copy_(torch.from_numpy(scs[0]["masks"])[None])
+        frame_work()
+        ctx.sync()
+        ctx.graph_begin()
+        frame_work()
+        gr = ctx.graph_end()
+        lat = []
+        for i in range(104):
+            sc = scs[i % len(scs)]
+            h_pts.copy_(torch.from_numpy(sc["points"]))
+            h_masks.copy_(torch.from_numpy(sc["masks"])[None])
+            time.sleep(0.002)                                # a sensor does not deliver frames back to back
+            t0 = time.perf_counter()
+            ctx.graph_launch(gr)
+            ctx.sync()
+            lat.append(time.perf_counter() - t0)
+            if i < len(scs):
+                sm = np.frombuffer(h_sum.numpy().tobytes(), SUMMARY_DTYPE)[0]
+                ref = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=orc.pack_masks(sc["masks"], 1, H, W), M=M,
+                              corners=scs[0]["corners_velo"], want_float=False)
+                if not (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(sm["inst_count"][:M], ref["inst_count"])
+                        and np.array_equal(h_cnt.numpy().reshape(M, B), ref["count_mb"]) and np.array_equal(sm["best_box"][:M], ref["best_box"])):
+                    raise SystemExit("bench secondary configs[4]: GPU result differs from the CPU oracle")
+        ctx.graph_destroy(gr)
+        lat = 1e3 * np.array(lat[4:])
+        out["configs4_stream_hipgraph_per_frame"] = {
+            "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "max_ms": float(lat.max()),
+            "frames": int(len(lat)), "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "budget_ms_at_10Hz": 100.0,
+            "includes": "H2D of points + masks (pinned), mask pack + erosion, project+label, lists + box counts, finalize, D2H of counts + summary",
+            "checked": "n_valid, inst_count, count_mb, best_box of the first 4 frames == CPU oracle"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,15 +359,27 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (one context each) the steps alternate over; 2 overlaps the short kernels of one "
                          "step with the streaming kernel of the next (higher points/s, longer per-kernel durations)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="overlap a step's short tail kernels (scan, lists, finalize) with the next step's streaming kernel on "
-                         "a second stream: more points/s, but the streaming kernel's own duration grows under the contention")
+    ap.add_argument("--mode", default=DEFAULT_MODE, choices=sorted(MODES),
+                    help="how a step's kernels are queued: " + "; ".join("%s = %s" % (k, v[3]) for k, v in sorted(MODES.items())))
+    ap.add_argument("--pipeline", action="store_true", help="same as --mode pipeline")
+    ap.add_argument("--side-cus", type=int, default=-1, help="override the mode's CU partition (multiple of 8, 0 = none)")
+    ap.add_argument("--exclusive", action="store_true", help="with a CU partition: the main stream runs on the other CUs only")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path without RCCL")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the second, event-bracketed pass")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (N = 1 only anyway)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the launcher command of --gpus N and exit (tests)")
     args = ap.parse_args()
+    if args.pipeline:
+        args.mode = "pipeline"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.dry_launch:
+            print(json.dumps({"would_launch": args.gpus}))
+            return 0
+        return launch_ranks(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -152,9 +388,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                                            # the launcher is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     if args.force_device >= 0:
@@ -190,26 +424,28 @@ def main():
             pts_dev.append(base_pts[perm].contiguous())
             del perm
         masks_dev.append(masks0.clone() if b else masks0)
-        outs.append(dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev),
-                         label_bits=torch.empty(ntot, dtype=torch.int32, device=dev),
-                         valid_idx=torch.empty(ntot, dtype=torch.int64, device=dev),
-                         inst_idx=torch.empty(ntot, dtype=torch.int64, device=dev),
-                         count_mb=torch.zeros(F * N_MASKS * N_BOXES, dtype=torch.int32, device=dev),
-                         summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev)))
+        outs.append(make_outputs(torch, dev, ntot, F, ntot, N_MASKS, F * N_BOXES, SUMMARY_DTYPE.itemsize))
     frame_off = np.arange(F + 1, dtype=np.int64) * n
 
-    # steps alternate over `streams` contexts (own HIP stream + scratch each), so the short
-    # latency-bound kernels of one step overlap the bandwidth-bound kernel of the next
+    # Contexts run on streams of their own (a CU partition needs that).  Everything above was queued on torch's
+    # current stream, and the caching allocator may have carved the output tensors from memory that kernels still
+    # queued there read (the index tensors of the gathers): each context gets an explicit device-side edge behind
+    # that stream before its first kernel, instead of relying on a device-wide synchronisation ("The
+    # bench_s1 fault").
+    pipelined, pack_side, side_cus, _ = MODES[args.mode]
+    if args.side_cus >= 0:
+        side_cus = args.side_cus
     nstream = max(1, min(args.streams, nbuf))
     nbuf -= nbuf % nstream                                  # buffer b always belongs to context b % nstream
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstream - 1)]
     ctxs = []
-    for st in streams:
+    for _ in range(nstream):
         c = LpfContext(local_rank)
-        c.set_stream(st.cuda_stream)
-        c.set_pipelined(args.pipeline)
+        if side_cus:
+            c.set_cu_partition(side_cus, exclusive=args.exclusive)
+        c.set_pipelined(pipelined, pack_side=pack_side)
         c.set_camera(T, K, W, H, 0.0, DMAX)
         c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
+        c.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctxs.append(c)
     ctx = ctxs[0]
 
@@ -241,7 +477,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    torch.cuda.synchronize(dev)                                     # inputs were produced on torch's stream
     for i in range(args.warmup):
         steps_fn[i % nbuf]()
     torch.cuda.synchronize(dev)
@@ -272,9 +507,14 @@ def main():
               and np.array_equal(outs[b]["count_mb"][:N_MASKS * N_BOXES].cpu().numpy().reshape(N_MASKS, N_BOXES), o["count_mb"])
               and np.array_equal(outs[b]["valid_idx"][:o["n_valid"]].cpu().numpy(), o["valid_idx"])
               and np.array_equal(outs[b]["uv"][:n].cpu().numpy(), np.stack([o["u"], o["v"]], axis=1))
-              and np.array_equal(outs[b]["label_bits"][:n].cpu().numpy().view(np.uint32), o["label_bits"]))
+              and np.array_equal(outs[b]["label_bits"][:n].cpu().numpy().view(np.uint32), o["label_bits"])
+              and np.array_equal(sm[0]["best_box"][:N_MASKS], o["best_box"]))
         if not ok:
             raise SystemExit("bench: GPU result differs from the CPU oracle -- refusing to report a number")
+
+    for c in ctxs:
+        c.close()
+    del steps_fn, pts_dev, masks_dev, outs, base_pts, masks0
 
     if rank == 0:
         total_points = float(ntot) * args.steps * world
@@ -295,14 +535,18 @@ def main():
                                    "masks + %d 3D boxes, V4 clip depth<30; one launch set per step produces all outputs "
                                    "(u,v,label,valid_idx,instance lists,count_mb,best box)" % (F, n, N_MASKS, N_BOXES),
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
-                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream, "tail_kernels_overlap_next_step": bool(args.pipeline),
+                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream,
+                       "mode": args.mode, "tail_kernels_overlap_next_step": bool(pipelined), "mask_pack_on_side_stream": bool(pack_side),
+                       "side_stream_cus": side_cus, "main_stream_excludes_them": bool(args.exclusive and side_cus),
+                       "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                        "sharding": "clouds per rank, no data-path collective"},
         }
         if k1_n:
             dur_s = 1e-3 * k1_ms / k1_n                              # mean event bracket around the kernel
             achieved = ALGO_BYTES_PER_POINT * ntot / dur_s / 1e9
+            traffic, traffic_note = pmc_traffic(ntot)
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(ntot),
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                 "kernel": "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "empty_bracket_us": 1e3 * empty_ms,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,
@@ -314,13 +558,14 @@ def main():
                                        % (args.steps, 1e3 * elapsed_ev / args.steps)}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(scenes[0], T, K, W, H, args.cpu_seconds)
+        if world == 1 and not args.no_secondary:
+            line["secondary"] = secondary_lines(torch, dev, local_rank, T, K, W, H)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -32,7 +32,9 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 2          /* 2: lpf_outputs gained uv_valid / label_valid */
+#define LPF_ABI_VERSION 3          /* 2: lpf_outputs gained uv_valid / label_valid
+                                      3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
+                                         lpf_set_pipelined modes; lpf_set_cu_partition; stale graphs are refused */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -87,14 +89,37 @@ int  lpf_abi_version(void);
 int  lpf_create(lpf_ctx **out, int device_id);
 void lpf_destroy(lpf_ctx *ctx);
 const char *lpf_last_error(const lpf_ctx *ctx);      /* ctx may be NULL: error of the last failed lpf_create */
-/* Run on a stream the caller owns (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Run on a stream the caller owns, e.g. torch.cuda.current_stream().cuda_stream.  The handle is used as it is:
+ * NULL (0) is the null stream -- which is what torch's default stream is -- so device-mode calls are ordered
+ * with the caller's other work on that stream and need no device-wide synchronisation.  A new context runs on an
+ * internal non-blocking stream; lpf_use_own_stream() goes back to one. */
 int  lpf_set_stream(lpf_ctx *ctx, void *hip_stream);
+int  lpf_use_own_stream(lpf_ctx *ctx);
+/* Ordering contract of device mode.  Every device pointer handed to lpf_set_masks_* / lpf_run* is read or written by
+ * kernels on the context's stream(s), in the order of the calls, and by nothing else.  A context that shares the
+ * caller's stream (lpf_set_stream) is ordered with the caller's work by the stream itself.  A context on its own
+ * stream is NOT: inputs produced on another stream, and -- with a stream-ordered caching allocator such as torch's
+ * -- even output buffers, whose memory may still be in use by kernels queued earlier on the allocating stream, need an
+ * edge first.  lpf_wait_for_stream makes the context's stream(s) wait, on the device, for everything queued so far
+ * on producer; lpf_release_to_stream makes consumer wait for everything the context has queued (tail and pack
+ * streams of the pipelined mode included).  Neither blocks the host.  (A missing edge is how round 1's bench once
+ * died inside torch's set-up gather: DESIGN.md, "The bench_s1 fault".) */
+int  lpf_wait_for_stream(lpf_ctx *ctx, void *producer_stream);
+int  lpf_release_to_stream(lpf_ctx *ctx, void *consumer_stream);
 int  lpf_sync(lpf_ctx *ctx);
-/* Pipelined device-mode runs: the short tail kernels of a run (segment scan, list building,
+/* Pipelined device-mode runs.  on = 1: the short tail kernels of a run (segment scan, list building,
  * per-frame summary) execute on a second, internal stream and overlap the streaming kernel of
- * the next run, which uses a second set of scratch buffers.  With it on, the outputs of a run are
- * complete after lpf_sync(), not after the caller's stream alone.  Off by default. */
+ * the next run, which uses a second set of scratch buffers.  on = 3: in addition device-mode
+ * lpf_set_masks_* pack on a third internal stream, into the label images of the NEXT run, so the pack overlaps
+ * the streaming kernel already queued; the mask tensor must then be complete when lpf_set_masks_* is
+ * called (the side stream does not wait for the caller's stream).  With either on, the outputs of a run are
+ * complete after lpf_sync(), not after the caller's stream alone.  0 = off (default). */
 int  lpf_set_pipelined(lpf_ctx *ctx, int on);
+/* Confine the internal side streams of the pipelined mode to side_cus compute units (a multiple of 8: the same
+ * share of each of the 8 XCDs; 0 = no confinement), so the tail kernels do not take issue slots from the
+ * streaming kernel everywhere.  exclusive = 1 additionally confines the context's OWN main stream to the
+ * remaining CUs (not possible on a caller's stream).  Call before lpf_set_pipelined or at any idle point. */
+int  lpf_set_cu_partition(lpf_ctx *ctx, int side_cus, int exclusive);
 /* The list/box-count kernel exists in two forms with identical results: one wave per 4096-point segment
  * (fewest instructions; right for big sparse batches that fill the chip) and one block of four or eight waves per
  * segment (right for a single frame or a batch of real frames, whose segments on cars hold hundreds of
@@ -175,7 +200,11 @@ int lpf_prepare_boxes(lpf_ctx *ctx, const double *corners_cam0, int nbox, const 
  * baked in; the caller may add its own async copies on the same stream in between).  lpf_graph_end
  * instantiates the graph; lpf_graph_launch replays it on the context's stream.  The context must
  * have run the same shapes once before capture (so no allocation or table upload happens inside
- * it), and pipelining must be off.  For launch-bound per-frame loops (10 Hz streaming). */
+ * it), and pipelining must be off.  For launch-bound per-frame loops (10 Hz streaming).
+ * A graph points into buffers and tables the context owns.  Anything that moves or rewrites them after the
+ * capture -- a run with another batch geometry, lpf_set_boxes, lpf_set_camera, lpf_set_stream, a mode switch, a
+ * call that had to grow a scratch buffer -- makes the graph stale: lpf_graph_launch then returns LPF_ERR_STATE
+ * instead of replaying it.  An error returned by a call made inside a capture abandons the capture. */
 typedef struct lpf_graph lpf_graph;
 int  lpf_graph_begin(lpf_ctx *ctx);
 int  lpf_graph_end(lpf_ctx *ctx, lpf_graph **out);

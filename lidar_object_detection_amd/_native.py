@@ -68,9 +68,13 @@ def load():
     lib.lpf_destroy.argtypes = [_P]
     lib.lpf_destroy.restype = None
     lib.lpf_set_stream.argtypes = [_P, _P]
+    lib.lpf_use_own_stream.argtypes = [_P]
+    lib.lpf_wait_for_stream.argtypes = [_P, _P]
+    lib.lpf_release_to_stream.argtypes = [_P, _P]
     lib.lpf_sync.argtypes = [_P]
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
     lib.lpf_set_list_kernel.argtypes = [_P, ctypes.c_int]
+    lib.lpf_set_cu_partition.argtypes = [_P, ctypes.c_int, ctypes.c_int]
     lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -101,8 +105,10 @@ def load():
     return lib
 
 
-EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_sync", "lpf_set_pipelined",
-            "lpf_set_list_kernel", "lpf_allreduce_metrics",
+EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
+            "lpf_release_to_stream", "lpf_sync",
+            "lpf_set_pipelined",
+            "lpf_set_list_kernel", "lpf_set_cu_partition", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
@@ -250,15 +256,36 @@ class LpfContext:
         self.close()
 
     def set_stream(self, stream_ptr):
-        self._check(self._lib.lpf_set_stream(self._h, _P(stream_ptr) if stream_ptr else None))
+        """Run on the caller's HIP stream, given by its handle (``torch.cuda.current_stream().cuda_stream``; 0 is the
+        null stream = torch's default stream).  ``None`` goes back to an internal stream of the context's own."""
+        if stream_ptr is None:
+            self._check(self._lib.lpf_use_own_stream(self._h))
+        else:
+            self._check(self._lib.lpf_set_stream(self._h, _P(int(stream_ptr))))
+
+    def wait_for_stream(self, stream_ptr):
+        """Device-side edge: the context's stream(s) wait for everything queued so far on ``stream_ptr`` (a HIP stream
+        handle, 0 = the null stream).  Needed when the context runs on its own stream and the inputs -- or the memory of
+        the output tensors -- were last touched on another stream."""
+        self._check(self._lib.lpf_wait_for_stream(self._h, _P(int(stream_ptr))))
+
+    def release_to_stream(self, stream_ptr):
+        """Device-side edge the other way: ``stream_ptr`` waits for everything this context has queued."""
+        self._check(self._lib.lpf_release_to_stream(self._h, _P(int(stream_ptr))))
 
     def sync(self):
         self._check(self._lib.lpf_sync(self._h))
 
-    def set_pipelined(self, on=True):
-        """Tail kernels of a device-mode run on a second stream (overlap with the next run); results
-        of a run are then complete after sync()."""
-        self._check(self._lib.lpf_set_pipelined(self._h, int(bool(on))))
+    def set_pipelined(self, on=True, pack_side=False):
+        """Tail kernels of a device-mode run on a second stream (overlap with the next run); with pack_side the
+        device-mode mask packing too (third stream; the masks must be complete when set_masks is called).
+        Results of a run are then complete after sync()."""
+        self._check(self._lib.lpf_set_pipelined(self._h, (3 if pack_side else 1) if on else 0))
+
+    def set_cu_partition(self, side_cus=0, exclusive=False):
+        """Confine the side streams of the pipelined mode to ``side_cus`` CUs (multiple of 8); with ``exclusive`` the
+        context's own main stream runs on the others."""
+        self._check(self._lib.lpf_set_cu_partition(self._h, int(side_cus), int(bool(exclusive))))
 
     def set_list_kernel(self, form="auto"):
         """Form of the list/box-count kernel: "auto" (by launch size), "block" or "wave" per segment; same results."""

@@ -36,10 +36,14 @@ struct DevBuf {                       // grow-only device buffer
 struct lpf_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    unsigned long long generation = 0;    // lpf_ctx::generation at capture time
 };
 
 struct lpf_ctx {
     bool capturing = false;
+    // Bumped by everything a captured graph bakes in and a later call may invalidate: buffer regrowth, frame-table
+    // upload, box / camera / stream / pipelining changes.  lpf_graph_launch refuses a graph of another generation.
+    unsigned long long generation = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -78,6 +82,9 @@ struct lpf_ctx {
     } sc[2];
     int parity = 0;
     bool pipelined = false;
+    bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
+    int tail_cus = 0;                 // > 0: stream_b / stream_c are confined to this many CUs (lpf_set_cu_partition)
+    bool cu_exclusive = false;        // ... and the context's own main stream to the others
     int list_form = 0;                // lpf_set_list_kernel: 0 by launch size, 1 block per segment, 2 wave per segment
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
@@ -104,6 +111,14 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     if (c) c->err = buf; else g_create_error = buf;
+    if (c && c->capturing) {              // an error inside a capture ends it: the stream must not stay in capture mode
+        c->capturing = false;
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(c->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        c->err += " [the graph capture in progress was abandoned]";
+    }
     return code;
 }
 
@@ -138,6 +153,7 @@ int reserve(lpf_ctx *c, DevBuf &b, size_t bytes, bool zero = false)
         if (rc_) return rc_;
         LPF_HIP(c, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
+        ++c->generation;                  // a captured graph may hold the freed pointer
     }
     const size_t want = bytes + bytes / 4;        // headroom against regrowth
     if (hipMalloc(&b.p, want) != hipSuccess) {
@@ -360,7 +376,7 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     // (Measured: packing on a side stream competes with the streaming kernel for HBM and lowers
     //  both the step rate and that kernel's bandwidth -- 136 vs 142 Gpoints/s -- so the pack stays on
     //  the caller's stream; the per-set label buffers keep the option open.)
-    const bool side = false;
+    const bool side = c->pack_side;
     const bool pipe = side && c->pipelined && on_device && !c->capturing;
     const bool per_set = c->pipelined && on_device && !c->capturing;
     int rc;
@@ -372,6 +388,8 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (F == 0) return LPF_OK;
     const size_t hw = (size_t)c->H * c->W;
     if ((rc = reserve(c, S.label_a, (size_t)F * hw * 4))) return rc;
+    // (mode 3 contract: the mask tensor is complete when this call is made -- the side stream does not wait for the
+    //  caller's stream, or the pack could not overlap the streaming kernel already queued there)
     if (pipe && S.k1_recorded) LPF_HIP(c, hipStreamWaitEvent(ms, S.k1_done, 0));   // the set's previous K1 still reads its label image
     const T *d_masks = masks;
     if (M > 0 && !on_device) {
@@ -453,12 +471,59 @@ int lpf_set_stream(lpf_ctx *c, void *s)
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     { int rc_ = sync_all(c); if (rc_) return rc_; }
+    if (c->cu_exclusive) return fail(c, LPF_ERR_STATE, "lpf_set_stream: the context runs an exclusive CU partition on its own stream; clear it first");
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
-    if (s) {
-        c->stream = (hipStream_t)s;
-    } else {
-        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
+    c->stream = (hipStream_t)s;          // NULL is the null stream itself (torch's default stream has handle 0)
+    ++c->generation;
+    return LPF_OK;
+}
+
+int lpf_use_own_stream(lpf_ctx *c)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    { int rc_ = sync_all(c); if (rc_) return rc_; }
+    if (c->own_stream) return LPF_OK;
+    c->stream = nullptr;
+    LPF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    ++c->generation;
+    return LPF_OK;
+}
+
+// ---- explicit ordering against the caller's other streams (no device-wide synchronisation) ---------------
+int lpf_wait_for_stream(lpf_ctx *c, void *producer)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_wait_for_stream inside graph capture");
+    if ((hipStream_t)producer == c->stream) return LPF_OK;      // same stream: already ordered
+    hipEvent_t e;
+    LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, (hipStream_t)producer);
+    if (r == hipSuccess) r = hipStreamWaitEvent(c->stream, e, 0);
+    // side streams only ever start behind an event of the main stream, except the mode-3 mask pack
+    if (r == hipSuccess && c->stream_c && c->pack_side) r = hipStreamWaitEvent(c->stream_c, e, 0);
+    (void)hipEventDestroy(e);                                  // released once it has completed
+    if (r != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_wait_for_stream: %s", hipGetErrorString(r));
+    return LPF_OK;
+}
+
+int lpf_release_to_stream(lpf_ctx *c, void *consumer)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_release_to_stream inside graph capture");
+    hipStream_t src[3] = {c->stream, c->stream_b, c->stream_c};
+    for (int i = 0; i < 3; ++i) {
+        if (i > 0 && !src[i]) continue;
+        if (src[i] == (hipStream_t)consumer) continue;
+        hipEvent_t e;
+        LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipError_t r = hipEventRecord(e, src[i]);
+        if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)consumer, e, 0);
+        (void)hipEventDestroy(e);
+        if (r != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_release_to_stream: %s", hipGetErrorString(r));
     }
     return LPF_OK;
 }
@@ -475,6 +540,36 @@ int lpf_set_list_kernel(lpf_ctx *c, int form)
     if (!c) return LPF_ERR_ARG;
     if (form < 0 || form > 2) return fail(c, LPF_ERR_ARG, "lpf_set_list_kernel: form=%d (0 auto, 1 block per segment, 2 wave per segment)", form);
     c->list_form = form;
+    ++c->generation;
+    return LPF_OK;
+}
+
+// stream_b / stream_c (re)created as the partition says; called with every stream idle
+static int make_side_streams(lpf_ctx *c)
+{
+    if (c->stream_b) { (void)hipStreamDestroy(c->stream_b); c->stream_b = nullptr; }
+    if (c->stream_c) { (void)hipStreamDestroy(c->stream_c); c->stream_c = nullptr; }
+    if (c->tail_cus > 0) {
+        // Bit i of a queue's CU mask: consecutive bits go round the XCDs first (measured with tools/cumask_probe:
+        // the low 8k bits are k CUs on each of the 8 XCDs), so "the low tail_cus bits" is an even slice of every XCD.
+        hipDeviceProp_t prop;
+        LPF_HIP(c, hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        if (c->tail_cus >= ncu) return fail(c, LPF_ERR_ARG, "cu partition: %d of %d CUs for the side streams leaves none", c->tail_cus, ncu);
+        std::vector<uint32_t> side((size_t)words, 0u), rest((size_t)words, 0u);
+        for (int i = 0; i < ncu; ++i) (i < c->tail_cus ? side : rest)[(size_t)i / 32] |= 1u << (i % 32);
+        LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream_b, (uint32_t)words, side.data()));
+        LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream_c, (uint32_t)words, side.data()));
+        if (c->cu_exclusive) {
+            if (!c->own_stream) return fail(c, LPF_ERR_STATE, "an exclusive CU partition needs the context's own stream (lpf_set_stream was given the caller's)");
+            (void)hipStreamDestroy(c->stream);
+            c->stream = nullptr;
+            LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, rest.data()));
+        }
+    } else {
+        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    }
     return LPF_OK;
 }
 
@@ -482,10 +577,10 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
+    if (on < 0 || on > 3 || on == 2) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 3 = 1 + mask packing on a side stream)", on);
     int rc = sync_all(c);
     if (rc) return rc;
-    if (on && !c->stream_b) LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-    if (on && !c->stream_c) LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    if (on && !c->stream_b && (rc = make_side_streams(c))) return rc;
     for (auto &S : c->sc) {
         if (on && !S.k1_done) {
             LPF_HIP(c, hipEventCreateWithFlags(&S.k1_done, hipEventDisableTiming));
@@ -494,7 +589,28 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
         }
     }
     c->pipelined = on != 0;
+    c->pack_side = on == 3;
     c->parity = 0;
+    ++c->generation;
+    return LPF_OK;
+}
+
+int lpf_set_cu_partition(lpf_ctx *c, int side_cus, int exclusive)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (side_cus < 0 || (side_cus & 7)) return fail(c, LPF_ERR_ARG, "lpf_set_cu_partition: side_cus=%d (0 = none, else a multiple of 8: the same share of every XCD)", side_cus);
+    int rc = sync_all(c);
+    if (rc) return rc;
+    if (c->cu_exclusive && c->own_stream && !(side_cus > 0 && exclusive)) {      // back to an unmasked main stream
+        (void)hipStreamDestroy(c->stream);
+        c->stream = nullptr;
+        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
+    c->tail_cus = side_cus;
+    c->cu_exclusive = side_cus > 0 && exclusive != 0;
+    ++c->generation;
+    if (c->stream_b || c->cu_exclusive) return make_side_streams(c);
     return LPF_OK;
 }
 
@@ -509,6 +625,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
     c->have_camera = true;
     c->cand_dirty = true;                    // the candidate grid depends on T, K, W, H
+    ++c->generation;                         // T, K, W, H are kernel arguments of a captured graph
     return LPF_OK;
 }
 
@@ -576,6 +693,7 @@ int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int
     if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "set_boxes: F=%d box_off=%p", F, (const void *)box_off);
     c->box_F = 0; c->box_off.clear();
     { int rc_ = sync_all(c); if (rc_) return rc_; }       // the tail kernels of a pending run may still read the tables
+    ++c->generation;                                      // box tables are rewritten (and may move)
     if (F == 0) return LPF_OK;
     if (box_off[0] != 0) return fail(c, LPF_ERR_ARG, "set_boxes: box_off[0] must be 0");
     for (int f = 0; f < F; ++f)
@@ -738,6 +856,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         }
         LPF_HIP(c, hipStreamSynchronize(c->stream));
         c->h_frames_dev = c->h_frames;
+        ++c->generation;                  // graphs captured for another geometry read these tables
     }
     if (pipe && S.tail_pending) LPF_HIP(c, hipStreamWaitEvent(c->stream, S.tail_done, 0));   // this set's previous tail
     if (pipe && S.mask_pending) { LPF_HIP(c, hipStreamWaitEvent(c->stream, S.mask_done, 0)); S.mask_pending = false; }
@@ -984,6 +1103,7 @@ int lpf_graph_end(lpf_ctx *c, lpf_graph **out)
         return fail(c, LPF_ERR_HIP, "graph capture failed: %s (a call inside the capture allocated, copied from pageable memory or synchronised?)",
                     hipGetErrorString(e));
     }
+    g->generation = c->generation;
     *out = g;
     return LPF_OK;
 }
@@ -992,6 +1112,9 @@ int lpf_graph_launch(lpf_ctx *c, lpf_graph *g)
 {
     if (!c || !g || !g->exec) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
+    if (g->generation != c->generation)
+        return fail(c, LPF_ERR_STATE, "lpf_graph_launch: the graph is stale -- since its capture the context changed geometry, boxes, camera, "
+                                      "stream or mode, or regrew a buffer the graph points into; capture it again");
     LPF_HIP(c, hipGraphLaunch(g->exec, c->stream));
     return LPF_OK;
 }

@@ -517,7 +517,11 @@ __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, uns
 template <unsigned FL2>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
 {
+#ifdef LPF_LAB_SMALL_LIDX
+    __shared__ unsigned short s_lidx[LPF_K2_WAVES][1024];   // LAB ONLY: sparse synthetic data
+#else
     __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // valid, then masked points (segment-relative)
+#endif
     __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz of the current 64 masked points
     __shared__ float4 s_bq[LPF_K2_WAVES][2 * 64];                      // {lo, hi} of the current <= 64 boxes
     __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds

@@ -285,18 +285,24 @@ def test_full_size_properties_2m(ctx, calib):
     _compare(r, o, 8, want_float=False)
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("pipelined", [False, True, "pack_side", "cus32", "cus64_exclusive_pack_side"])
 def test_device_mode_back_to_back_runs(calib, pipelined):
     """Device-pointer mode (torch tensors): several different batches enqueued back to back without
-    host syncs, with and without the tail kernels on a second stream; every run must equal the oracle."""
+    host syncs, with and without the tail kernels on a second stream (optionally with the mask pack on a third, and
+    with the side streams confined to a CU partition); every run must equal the oracle."""
     import torch
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     _, T, K, W, H = S.default_calibration(calib)
     dev = torch.device("cuda", 0)
     ctx = LpfContext(0)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.set_pipelined(pipelined)
+    if pipelined == "cus64_exclusive_pack_side":
+        ctx.set_cu_partition(64, exclusive=True)            # needs the context's own stream
+    else:
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        if pipelined == "cus32":
+            ctx.set_cu_partition(32)
+    ctx.set_pipelined(bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     F, M, Bx = 3, 5, 7
     runs = []

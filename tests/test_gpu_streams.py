@@ -1,0 +1,131 @@
+"""Stream-ordering contract of device mode (include/lpf.h, "Ordering contract") and staleness of captured graphs.
+
+Round 1's bench once died inside torch's set-up gather (gpurun_out/bench_s1.*: HSA_STATUS_ERROR_EXCEPTION 0x1016 =
+a device-side abort() of torch's index bounds check): `set_stream(0)` silently detached the context from torch's
+default stream, so its warm-up kernels wrote into an output tensor whose memory the caching allocator had recycled
+from an index tensor that a still-queued gather was going to read.  These tests pin the fixed behaviour: handle 0 is
+honoured, and a context on its own stream gets explicit device-side edges -- both without any device-wide sync.
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _delayed_inputs(torch, dev, sc):
+    """Points and masks that only become correct at the END of a long chain of kernels on the current stream: a consumer
+    that is not ordered behind that stream sees zeros."""
+    a = torch.randn(4096, 4096, device=dev)
+    for _ in range(40):                                     # tens of milliseconds of queued work
+        a = (a @ a).clamp_(-1.0, 1.0)
+    gate = (a.sum() * 0.0).to(torch.float32)                # 0.0, available only when the chain is done
+    pts = torch.zeros((len(sc["points"]), 4), dtype=torch.float32, device=dev)
+    pts.add_(torch.from_numpy(sc["points"]).to(dev, non_blocking=True) + gate)
+    masks = torch.zeros(sc["masks"].shape, dtype=torch.uint8, device=dev)
+    masks.add_(torch.from_numpy(sc["masks"]).to(dev, non_blocking=True) + gate.to(torch.uint8))
+    return pts, masks
+
+
+def _outputs(torch, dev, n, M, Bx, summary_bytes):
+    return dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty(n, dtype=torch.int64, device=dev),
+                count_mb=torch.zeros(M * Bx, dtype=torch.int32, device=dev),
+                summary=torch.zeros(summary_bytes, dtype=torch.uint8, device=dev))
+
+
+def _check(o, sc, T, K, W, H, M, Bx, summary_dtype):
+    # .cpu() runs on torch's current stream: it is ordered behind the context's work by the stream / the release edge
+    sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), summary_dtype)[0]
+    ref = orc.run(sc["points"], T, K, W, H, 0.0, 30.0, label_img=orc.pack_masks(sc["masks"], 0, H, W), M=M,
+                  corners=sc["corners_velo"], want_float=False)
+    uv = o["uv"].cpu().numpy()
+    assert np.array_equal(uv[:, 0], ref["u"]) and np.array_equal(uv[:, 1], ref["v"])
+    assert np.array_equal(o["label_bits"].cpu().numpy().view(np.uint32), ref["label_bits"])
+    assert int(sm["n_valid"]) == ref["n_valid"] and ref["n_valid"] > 1000
+    assert np.array_equal(o["valid_idx"].cpu().numpy()[:ref["n_valid"]], ref["valid_idx"])
+    assert np.array_equal(sm["inst_count"][:M], ref["inst_count"]) and int(ref["inst_count"].sum()) > 0
+    assert np.array_equal(o["count_mb"].cpu().numpy().reshape(M, Bx), ref["count_mb"])
+
+
+@pytest.mark.parametrize("how", ["shared_default_stream", "own_stream_with_edges", "own_stream_pipelined_with_edges"])
+def test_device_mode_is_ordered_without_a_device_sync(calib, how):
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    n, M, Bx = 200_000, 6, 9
+    sc = S.scene(n, n_masks=M, n_boxes=Bx, seed=77)
+    cur = torch.cuda.current_stream(dev)
+    assert cur.cuda_stream == 0, "this test wants torch's default (null) stream"
+    with LpfContext(0) as ctx:
+        if how == "shared_default_stream":
+            ctx.set_stream(cur.cuda_stream)                 # handle 0: the null stream itself
+        elif how == "own_stream_pipelined_with_edges":
+            ctx.set_pipelined(True, pack_side=True)
+        ctx.set_camera(T, K, W, H, 0.0, 30.0)
+        ctx.set_boxes(sc["corners_velo"])
+        # warm run on other data: scratch allocation / table uploads (which synchronise) happen here, not below
+        warm = S.scene(n, n_masks=M, n_boxes=Bx, seed=78)
+        ow = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        ctx.set_masks(torch.from_numpy(warm["masks"]).to(dev))
+        ctx.run_device(torch.from_numpy(warm["points"]).to(dev), np.array([0, n], np.int64), inst_cap=n, **ow)
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        # ---- from here on: no host-side wait until the results are read ----
+        pts, masks = _delayed_inputs(torch, dev, sc)
+        o = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        if how != "shared_default_stream":
+            ctx.wait_for_stream(cur.cuda_stream)
+        ctx.set_masks(masks)
+        ctx.run_device(pts, np.array([0, n], np.int64), inst_cap=n, **o)
+        if how != "shared_default_stream":
+            ctx.release_to_stream(cur.cuda_stream)
+        _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+
+
+def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, LpfError, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    n, M, Bx = 50_000, 4, 5
+    sc = S.scene(n, n_masks=M, n_boxes=Bx, seed=91)
+    with LpfContext(0) as ctx:
+        ctx.set_camera(T, K, W, H, 0.0, 30.0)
+        ctx.set_boxes(sc["corners_velo"])
+        pts = torch.from_numpy(sc["points"]).to(dev)
+        masks = torch.from_numpy(sc["masks"]).to(dev).unsqueeze(0)
+        o = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        torch.cuda.synchronize(dev)
+        step = ctx.make_device_step(pts, np.array([0, n], np.int64), masks_u8=masks, inst_cap=n, **o)
+        step()
+        ctx.sync()
+        ctx.graph_begin()
+        step()
+        g = ctx.graph_end()
+        ctx.graph_launch(g)                                 # fresh: replays
+        ctx.sync()
+        _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+        # another geometry rewrites the frame table the graph points at -> the graph must be refused afterwards
+        half = make = ctx.make_device_step(pts[:n // 2], np.array([0, n // 2], np.int64), masks_u8=masks, inst_cap=n, **o)
+        half()
+        ctx.sync()
+        with pytest.raises(LpfError) as ei:
+            ctx.graph_launch(g)
+        assert ei.value.code == -3 and "stale" in str(ei.value)
+        ctx.graph_destroy(g)
+        # an error inside a capture (here: a geometry that needs a table upload, which cannot be captured) abandons the
+        # capture instead of leaving the stream in capture mode
+        ctx.graph_begin()
+        with pytest.raises(LpfError):
+            step()                                          # full size again: frame table differs -> needs a sync
+        with pytest.raises(LpfError):
+            ctx.graph_end()                                 # nothing is being captured any more
+        step()                                              # and the context is usable
+        ctx.sync()
+        _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+        del make

@@ -199,6 +199,31 @@ int main(int argc, char **argv)
         timeit2("k2 NOBOX NOINST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
         P.valid_idx = nullptr; P.inst_idx = nullptr; P.boxp = nullptr; P.boxq = nullptr; P.cnt = nullptr;
     }
+    {   // ---- occupancy sweep: how many resident blocks per CU does the kernel need to hold its bandwidth?  A dynamic-LDS
+        //      pad caps the blocks a CU admits (160 KB / pad); tail kernels running beside K1 take wave slots the same way.
+        const int nseg = (N + LPF_SEG_QUANTUM - 1) / LPF_SEG_QUANTUM;
+        LpfFrame fr; memset(&fr, 0, sizeof fr); fr.N = N; fr.nseg = nseg;
+        P.seg_pts = LPF_SEG_QUANTUM; P.nseg_total = nseg; P.nseg_cap = nseg; P.frame0 = fr; P.F = 1;
+        printf("%-10s %6s %10s %10s\n", "rows", "blk/CU", "us/launch", "GB/s(28B)");
+        auto sweep = [&](const char *name, auto kern, int rows) {
+            for (int occ : {8, 6, 5, 4, 3, 2}) {
+                const size_t pad = (size_t)(160 * 1024 / occ) - 1024;
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                const dim3 g(nseg * (LPF_SEG_QUANTUM / (LPF_BLOCK * rows)));
+                for (int it = 0; it < 12; ++it) { P.pts = pts[it % NBUF]; P.uv = uv[it % NBUF]; P.label_bits = lab[it % NBUF]; hipLaunchKernelGGL(kern, g, dim3(LPF_BLOCK), pad, s, P); }
+                CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
+                for (int it = 0; it < ITERS; ++it) { P.pts = pts[it % NBUF]; P.uv = uv[it % NBUF]; P.label_bits = lab[it % NBUF]; hipLaunchKernelGGL(kern, g, dim3(LPF_BLOCK), pad, s, P); }
+                CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                const double us = 1e3 * ms / ITERS;
+                printf("%-10s %6d %10.2f %10.1f\n", name, occ, us, 28.0 * N / us / 1e3);
+            }
+        };
+        sweep("rows 2", lpf_k1_project_t<2, BEST, uint8_t>, 2);
+        sweep("rows 4", lpf_k1_project_t<4, BEST, uint8_t>, 4);
+        sweep("rows 8", lpf_k1_project_t<8, BEST, uint8_t>, 8);
+        sweep("rows 16", lpf_k1_project_t<16, BEST, uint8_t>, 16);
+    }
     const int segmul[] = {1};
     printf("%-34s %8s %8s %10s %10s\n", "variant", "seg_pts", "blocks", "us/launch", "GB/s(28B)");
     for (const Variant &v : vars) {
