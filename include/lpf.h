@@ -120,11 +120,13 @@ int  lpf_set_pipelined(lpf_ctx *ctx, int on);
  * streaming kernel everywhere.  exclusive = 1 additionally confines the context's OWN main stream to the
  * remaining CUs (not possible on a caller's stream).  Call before lpf_set_pipelined or at any idle point. */
 int  lpf_set_cu_partition(lpf_ctx *ctx, int side_cus, int exclusive);
-/* The list/box-count kernel exists in two forms with identical results: one wave per 4096-point segment
- * (fewest instructions; right for big sparse batches that fill the chip) and one block of four or eight waves per
- * segment (right for a single frame or a batch of real frames, whose segments on cars hold hundreds of
- * masked points).  0 = choose by launch size (default), 1 = block per segment, 2 = wave per segment. */
-int  lpf_set_list_kernel(lpf_ctx *ctx, int form);
+
+/* Launch geometry.  A run cuts every frame into segments -- one list wave each -- and K1 tiles: 1024-point segments of
+ * 512-point tiles for launches of up to 4 Mi points (a real frame is then ~107 waves instead of 27), 4096-point
+ * segments of 1024-point tiles beyond.  Results do not depend on it.  0 = by launch size (default), 1 = small,
+ * 2 = large, 3 = large with the segment prefixes taken from the scan kernel (what frames of more than 64 x 64
+ * segments get by themselves).  For tests and tuning. */
+int  lpf_set_geometry(lpf_ctx *ctx, int mode);
 
 /* ---- per-sequence state --------------------------------------------------------
  * Replaces V3:565-569 + V3:584 constants.  T = TrVeloToRect (row-major 4x4, V3:535),

@@ -73,8 +73,8 @@ def load():
     lib.lpf_release_to_stream.argtypes = [_P, _P]
     lib.lpf_sync.argtypes = [_P]
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
-    lib.lpf_set_list_kernel.argtypes = [_P, ctypes.c_int]
     lib.lpf_set_cu_partition.argtypes = [_P, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_geometry.argtypes = [_P, ctypes.c_int]
     lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -108,7 +108,7 @@ def load():
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
             "lpf_release_to_stream", "lpf_sync",
             "lpf_set_pipelined",
-            "lpf_set_list_kernel", "lpf_set_cu_partition", "lpf_allreduce_metrics",
+            "lpf_set_cu_partition", "lpf_set_geometry", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
@@ -287,9 +287,10 @@ class LpfContext:
         context's own main stream runs on the others."""
         self._check(self._lib.lpf_set_cu_partition(self._h, int(side_cus), int(bool(exclusive))))
 
-    def set_list_kernel(self, form="auto"):
-        """Form of the list/box-count kernel: "auto" (by launch size), "block" or "wave" per segment; same results."""
-        self._check(self._lib.lpf_set_list_kernel(self._h, {"auto": 0, "block": 1, "wave": 2}[form]))
+    def set_geometry(self, mode="auto"):
+        """Segment / tile sizes of a run: "auto" (by launch size), "small" (1024-point segments), "large" (4096) or
+        "large-scan" (4096, prefixes from the scan kernel); same results."""
+        self._check(self._lib.lpf_set_geometry(self._h, {"auto": 0, "small": 1, "large": 2, "large-scan": 3}[mode]))
 
     def allreduce_metrics(self, vec, rccl_comm, op="sum"):
         """In-place all-reduce of an int64 NumPy vector over an RCCL communicator (an ncclComm_t as an integer /

@@ -14,11 +14,9 @@
 #include <string>
 #include <vector>
 
-// Segments below which K2 runs one block (not one wave) per segment.  Measured on MI355X: on real-frame-shaped
-// batches (dense segments) the block form wins at every size tried (30 vs 82 us for 1 frame, 106 vs 127 us for
-// 64 frames = 1728 segments, 210 vs 224 us for 128 frames); on the sparse synthetic bench at 4096 segments the
-// wave form wins (19.8 vs 35.4 us).  The host cannot see the density, so the switch is by size.
-#define LPF_K2_BLOCK_BELOW 2048
+// Points per launch up to which a run uses the small geometry: 512-point K1 tiles and 1024-point segments (more,
+// shorter blocks and list waves: a single real frame is 107 segments instead of 27).
+#define LPF_SMALL_LAUNCH (4ll << 20)
 
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_k3_finalize");
 
@@ -73,7 +71,7 @@ struct lpf_ctx {
     // Scratch of one in-flight run.  Two sets: with pipelining on, the tail kernels of run i (second
     // stream) overlap the streaming kernel of run i+1 (caller's stream), which uses the other set.
     struct Scratch {
-        DevBuf vbal, mbal, seg_tab, seg_pre, frame_tot, cnt, mlist;
+        DevBuf vbal, mbal, seg_tab, grp_tab, frm_tab, seg_pre, cnt, mlist, mdense;
         DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
         void *label_cur = nullptr;
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
@@ -81,11 +79,11 @@ struct lpf_ctx {
         bool tail_pending = false, k1_recorded = false, mask_pending = false;
     } sc[2];
     int parity = 0;
+    int geometry = 0;                 // lpf_set_geometry: 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes
     bool pipelined = false;
     bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
     int tail_cus = 0;                 // > 0: stream_b / stream_c are confined to this many CUs (lpf_set_cu_partition)
     bool cu_exclusive = false;        // ... and the context's own main stream to the others
-    int list_form = 0;                // lpf_set_list_kernel: 0 by launch size, 1 block per segment, 2 wave per segment
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
@@ -448,7 +446,7 @@ void lpf_destroy(lpf_ctx *c)
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     if (c->stream_c) (void)hipStreamSynchronize(c->stream_c);
     for (auto &S : c->sc) {
-        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.seg_pre, &S.frame_tot, &S.cnt, &S.mlist, &S.label_a, &S.label_b};
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.mdense, &S.label_a, &S.label_b};
         for (DevBuf *b : sb) release(*b);
         if (S.k1_done) (void)hipEventDestroy(S.k1_done);
         if (S.tail_done) (void)hipEventDestroy(S.tail_done);
@@ -535,11 +533,11 @@ int lpf_sync(lpf_ctx *c)
     return sync_all(c);
 }
 
-int lpf_set_list_kernel(lpf_ctx *c, int form)
+int lpf_set_geometry(lpf_ctx *c, int mode)
 {
     if (!c) return LPF_ERR_ARG;
-    if (form < 0 || form > 2) return fail(c, LPF_ERR_ARG, "lpf_set_list_kernel: form=%d (0 auto, 1 block per segment, 2 wave per segment)", form);
-    c->list_form = form;
+    if (mode < 0 || mode > 3) return fail(c, LPF_ERR_ARG, "lpf_set_geometry: mode=%d (0 by launch size, 1 small, 2 large, 3 large with scan-kernel prefixes)", mode);
+    c->geometry = mode;
     ++c->generation;
     return LPF_OK;
 }
@@ -742,11 +740,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool host_io = !out->on_device;
     int rc;
 
-    // ---- segmentation: fixed 4096-point segments (one K2 wave or block each); K1 tiles subdivide them ------
-    const int64_t seg_pts = LPF_SEG_QUANTUM;
+    // ---- segmentation: segments of 4096 points (1024 for small launches), one list wave each; K1 tiles subdivide them;
+    //      groups of 64 segments are the second level of the counters ------------------------------------------------
+    const bool small = c->geometry == 1 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
+    const int64_t seg_pts = small ? LPF_SEG_SMALL : LPF_SEG_QUANTUM;
     if (c->box_F && c->cand_dirty && (rc = build_candidates(c, F))) return rc;
     c->h_frames.resize(F);
-    int nseg_total = 0;
+    int nseg_total = 0, ngrp_total = 0, max_ngrp = 0;
+    int64_t max_n = 0;
     for (int f = 0; f < F; ++f) {
         LpfFrame &fr = c->h_frames[f];
         fr.pt_off = frame_off[f];
@@ -760,10 +761,17 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.pad = f;
         fr.cand_off = c->box_F ? c->cand_off[f] : 0;
         fr.cand_words = (fr.B + 63) / 64;
-        fr.pad2 = 0;
+        fr.grp_off = ngrp_total;
+        const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
+        ngrp_total += ngrp;
+        if (ngrp > max_ngrp) max_ngrp = ngrp;
+        if (fr.N > max_n) max_n = fr.N;
     }
-    const int nseg_cap = nseg_total > 0 ? nseg_total : 1;
+    const int nseg_cap = nseg_total > 0 ? nseg_total : 1, ngrp_cap = ngrp_total > 0 ? ngrp_total : 1;
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
+    // a list wave sums one group's segments and the frame's groups, a lane each: frames of more than 64 groups
+    // (16.7 M points) take their prefixes from the scan kernel instead
+    const bool pre_scan = max_ngrp > 64 || c->geometry == 3;
 
     // pipelined device runs alternate between two scratch sets; everything else uses set 0 with both streams idle
     const bool pipe = c->pipelined && !host_io && pts_on_device;
@@ -774,8 +782,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if ((rc = reserve(c, S.vbal, rows * 8))) return rc;
     if ((rc = reserve(c, S.mbal, rows * 8))) return rc;
     if ((rc = reserve(c, S.seg_tab, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4), true))) return rc;
-    if ((rc = reserve(c, S.seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
-    if ((rc = reserve(c, S.frame_tot, (size_t)F * LPF_TAB_ROWS * 4))) return rc;
+    if ((rc = reserve(c, S.grp_tab, (size_t)LPF_TAB_GROUPS * ngrp_cap * sizeof(uint4), true))) return rc;
+    if ((rc = reserve(c, S.frm_tab, (size_t)F * LPF_FRM_SHARDS * LPF_TAB_GROUPS * sizeof(uint4), true))) return rc;
+    if (pre_scan && (rc = reserve(c, S.seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
     if (F > 1 && (rc = reserve(c, c->segs, (size_t)nseg_cap * sizeof(LpfFrame)))) return rc;
     if ((rc = reserve(c, S.cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
 
@@ -784,7 +793,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     memcpy(P.T, c->T, sizeof P.T);
     memcpy(P.K, c->K, sizeof P.K);
     P.dmin = c->dmin; P.dmax = c->dmax; P.W = c->W; P.H = c->H;
-    P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap;
+    P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap; P.ngrp_cap = ngrp_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
     P.label_img = (M > 0) ? S.label_cur : nullptr;
@@ -792,7 +801,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
-    P.seg_tab = (uint4 *)S.seg_tab.p; P.seg_pre = (uint4 *)S.seg_pre.p; P.frame_tot = (unsigned *)S.frame_tot.p;
+    P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
+    P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
@@ -839,6 +849,10 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (M > 0) {                         // K1 -> K2 hand-off of the masked points (sparse writes into N slots)
         if ((rc = reserve(c, S.mlist, n * 16))) return rc;
         P.mlist = (float4 *)S.mlist.p;
+        if (Btot > 0) {                  // ... and their dense per-frame copy, which the box-count kernel reads
+            if ((rc = reserve(c, S.mdense, n * 16))) return rc;
+            P.mdense = (float4 *)S.mdense.p;
+        }
     }
 
     // The frame table only changes when the batch geometry does; upload it then (and wait, the
@@ -874,9 +888,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             LPF_HIP(c, hipEventRecord(e0, c->stream));
         }
         // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
-        P.tile_pts = (Ntot <= (4ll << 20)) ? 512 : 1024;
-        const bool small = Ntot <= (4ll << 20);
-        const dim3 g1(nseg_total * (unsigned)(seg_pts / (small ? 512 : 1024)));
+        P.tile_pts = small ? 512 : 1024;
+        const dim3 g1(nseg_total * (unsigned)(seg_pts / P.tile_pts));
         const int lb = (M > 0) ? S.label_bytes : 4;
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
         if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
@@ -890,41 +903,27 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         S.k1_recorded = true;
         LPF_HIP(c, hipStreamWaitEvent(tail_stream, S.k1_done, 0));
     }
-    static const int k2_ablate = getenv("LPF_DEV_K2_ABLATE") ? atoi(getenv("LPF_DEV_K2_ABLATE")) : 0;   // profiling aid only
-    static const int k2_block_below = getenv("LPF_DEV_K2_BLOCK_BELOW") ? atoi(getenv("LPF_DEV_K2_BLOCK_BELOW")) : LPF_K2_BLOCK_BELOW;   // idem
-    const bool k2_block = !k2_ablate && (c->list_form == 1 || (c->list_form == 0 && nseg_total < k2_block_below));
-    int max_nseg = 0;
-    for (int f = 0; f < F; ++f) if (c->h_frames[f].nseg > max_nseg) max_nseg = c->h_frames[f].nseg;
-    // Frames of at most 64 segments (262 144 points) under the block form need no scan kernel: the blocks derive
-    // their prefixes from the segment counters themselves (one launch and ~6 us less per step on real frames).
-    P.inline_scan = (k2_block && max_nseg <= 64) ? 1 : 0;
-    if (!P.inline_scan) {
-        if (max_nseg <= 4 * LPF_BLOCK && (2 + M + 3) / 4 <= 3)          // <= 1024 segments per frame, M <= 10
-            hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
-        else
-            hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
-        LPF_HIP(c, hipGetLastError());
-    }
-    if (nseg_total > 0 && (P.valid_idx || P.inst_idx || (M > 0 && Btot > 0))) {
-        const dim3 g2((nseg_total + LPF_K2_WAVES - 1) / LPF_K2_WAVES);
-        if (k2_ablate == 4) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 8) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 2) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 16) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOEXACT>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 32) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 96) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOCAND | LPF_F2_LAB_NOPROJ>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_ablate == 12) hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        else if (k2_block)                                   // a block per segment (see lpf_k2_block)
-        {
-            // eight waves per segment while that still leaves SIMDs free (measured: 26.5 vs 30.6 us for one real frame,
-            // 51.2 vs 54.4 us for 20, 109.5 vs 108.3 us for 64 = 1728 segments), four beyond
-            static const int k2_nw_env = getenv("LPF_DEV_K2_NW") ? atoi(getenv("LPF_DEV_K2_NW")) : 0;   // profiling aid
-            const int k2_nw = k2_nw_env ? k2_nw_env : (nseg_total <= 1024 ? 8 : 4);
-            if (k2_nw == 4) hipLaunchKernelGGL((lpf_k2_block<4>), dim3(nseg_total), dim3(256), 0, tail_stream, P);
-            else hipLaunchKernelGGL((lpf_k2_block<8>), dim3(nseg_total), dim3(512), 0, tail_stream, P);
+    // ---- the tail: lists (one wave per segment), box counts (the frame's masked points, densely), per-frame summary ----
+    if (nseg_total > 0) {
+        if (pre_scan) {
+            hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
+            LPF_HIP(c, hipGetLastError());
         }
-        else hipLaunchKernelGGL((lpf_k2_lists), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-        LPF_HIP(c, hipGetLastError());
+        if (P.valid_idx || P.inst_idx || P.mdense) {
+            const dim3 g2((nseg_total + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES);
+            if (pre_scan) hipLaunchKernelGGL((lpf_lists_t<true>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+            else hipLaunchKernelGGL((lpf_lists_t<false>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
+            LPF_HIP(c, hipGetLastError());
+        }
+        if (P.mdense) {
+            // a frame's masked points are shared by up to `slices` blocks in chunks of 256; blocks past the end of the
+            // list leave at once (the host does not know how many points the masks caught)
+            long long slices = (max_n + 4095) / 4096, cap = 4096 / F;
+            if (slices > cap) slices = cap;
+            if (slices < 1) slices = 1;
+            hipLaunchKernelGGL(lpf_boxcount, dim3((unsigned)slices, (unsigned)F), dim3(LPF_BLOCK), 0, tail_stream, P);
+            LPF_HIP(c, hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
     LPF_HIP(c, hipGetLastError());

@@ -7,8 +7,9 @@
 //                      on an LDS-staged tile of packed bits                             (V3:82-97, V3:222)
 //   lpf_k1_project     float4 stream: 4x4 transform, cam2image, clip, label gather,
 //                      per-row wave ballots + per-segment counters                      (V3:565-569, 584, 225)
-//   lpf_k2_lists       ballots -> stable valid / per-instance index lists (wave prefix),
-//                      masked points x boxes slab test -> integer counters              (V3:585, 228, 187-202, 370)
+//   lpf_lists          ballots -> stable valid / per-instance index lists (wave prefix) and the frame's
+//                      dense list of masked points                                       (V3:585, 228)
+//   lpf_boxcount       masked points x candidate boxes, slab test -> integer counters    (V3:187-202, 370)
 //   lpf_k3_finalize    first-strict-max box scan + per-frame summary                    (V3:353-379)
 //
 // Arithmetic: everything the reference computes in float64 is float64 here, with the
@@ -19,7 +20,10 @@
 #include <stdint.h>
 
 #define LPF_BLOCK 256            // 4 waves of 64
-#define LPF_SEG_QUANTUM 4096     // points per segment = 64 ballot rows = one K2 wave; every K1 tile size divides it
+#define LPF_SEG_QUANTUM 4096     // points per segment of a big launch = 64 ballot rows = one list wave (small launches: LPF_SEG_SMALL)
+#define LPF_SEG_SMALL 1024       // ... of a small one: 16 rows, four times the waves for the same points; every K1 tile size divides both
+#define LPF_GROUP_SEGS 64        // segments per group (second level of the counters: one lane per segment / per group)
+#define LPF_FRM_SHARDS 8         // the frame-level counters are kept in 8 copies (segment index mod 8) so no address is hot
 #define LPF_MAX_MASKS_DEV 32     // = LPF_MAX_MASKS of include/lpf.h
 #define LPF_TAB_ROWS 36          // counters per segment: 0 valid, 1 masked, 2+m instance m (34 used)
 #define LPF_TAB_GROUPS 9         // stored as uint4 groups: counter c lives in group c>>2, component c&3
@@ -35,7 +39,7 @@ struct LpfFrame {                // one per frame, device + host copy
     int pad;                     // frame index (set by the host)
     long long cand_off;          // first word of the frame's candidate-box grid
     int cand_words;              // 64-bit words per grid cell = ceil(B / 64)
-    int pad2;
+    int grp_off;                 // first group (of LPF_GROUP_SEGS segments) of the frame
 };
 
 struct LpfParams {
@@ -44,9 +48,10 @@ struct LpfParams {
     double dmin, dmax;
     int W, H;
     int F, M;
-    int seg_pts;                 // points per segment (= LPF_SEG_QUANTUM)
+    int seg_pts;                 // points per segment: LPF_SEG_QUANTUM or LPF_SEG_SMALL
     int nseg_total;
     int nseg_cap;                // pitch (segments) of one seg_tab group
+    int ngrp_cap;                // pitch (groups) of one grp_tab group
     int oriented;
     long long inst_cap;
     LpfFrame frame0;             // the frame table by value when F == 1 (no dependent load)
@@ -72,14 +77,15 @@ struct LpfParams {
     unsigned long long *vbal, *mbal;   // one 64-bit ballot per 64 points
     uint4 *seg_tab;              // [LPF_TAB_GROUPS][nseg_cap] per-segment counters, 4 per uint4;
                                  // K1 tiles add into it, K3 leaves it zeroed
-    uint4 *seg_pre;              // [LPF_TAB_GROUPS][nseg_cap] written by the scan (see lpf_scan_segments)
-    unsigned *frame_tot;         // [F][LPF_TAB_ROWS] totals per frame
+    uint4 *grp_tab;              // [LPF_TAB_GROUPS][ngrp_cap] the same per group of LPF_GROUP_SEGS segments
+    uint4 *frm_tab;              // [F][LPF_FRM_SHARDS][LPF_TAB_GROUPS] ... and per frame (sum the shards)
+    uint4 *seg_pre;              // [LPF_TAB_GROUPS][nseg_cap] written by lpf_scan_segments (frames of more than 64 groups only)
     unsigned *cnt;               // [M*Btot] inside counts (self-cleaned by K3)
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
-                                 // bits} of its masked points in point order (K2 never gathers from the cloud)
+                                 // bits} of its masked points in point order (nothing gathers from the cloud later)
+    float4 *mdense;              // [Ntot] per frame, at its first point: the same entries densely, in point order
+                                 // (written by lpf_lists, read by lpf_boxcount); null when no box is to be counted
     int tile_pts;                // points per K1 tile of this launch (4 waves)
-    int inline_scan;             // 1: no scan kernel ran -- lpf_k2_block derives its prefixes from seg_tab, lpf_k3_finalize the
-                                 // totals (and cleans seg_tab); only when every frame has <= 64 segments
 };
 
 __device__ __forceinline__ int lpf_lane() { return threadIdx.x & 63; }
@@ -176,7 +182,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
 {
     // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
     constexpr int TILE = LPF_BLOCK * ROWS;
-    static_assert(LPF_SEG_QUANTUM % TILE == 0, "tiles must divide segments");
+    static_assert(LPF_SEG_QUANTUM % TILE == 0 && LPF_SEG_SMALL % TILE == 0, "tiles must divide segments");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const int tiles_per_seg = P.seg_pts / TILE;
     const int lb = lpf_xcd_remap(blk, P.nseg_total * tiles_per_seg);
@@ -292,8 +298,14 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
         // two 32-bit counters per 64-bit atomic: neither half can carry (each sum < 2^32)
         if (tid < (2 + P.M + 1) >> 1) {
             const unsigned long long v = (unsigned long long)s_cnt[2 * tid] | ((unsigned long long)s_cnt[2 * tid + 1] << 32);
-            if (v)
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.seg_tab + (size_t)(tid >> 1) * P.nseg_cap + sid) + (tid & 1), v);
+            if (v) {
+                // three levels -- segment, group of 64 segments, frame (8 shards) -- so that a list wave finds its
+                // segment's place in the frame's lists with two wave sums instead of a scan over the frame
+                const int k = sid - fr.seg_off, g = tid >> 1, h = tid & 1;
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.seg_tab + (size_t)g * P.nseg_cap + sid) + h, v);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.grp_tab + (size_t)g * P.ngrp_cap + fr.grp_off + (k >> 6)) + h, v);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + (k & (LPF_FRM_SHARDS - 1))) * LPF_TAB_GROUPS + g) + h, v);
+            }
         }
     }
 }
@@ -342,12 +354,47 @@ __device__ __forceinline__ bool lpf_aabb_inside(double px, double py, double pz,
 }
 
 // ------------------------------------------------------------------------------------
-// SCAN: one block per frame.  Turns the per-segment counters K1 accumulated into
-//   seg_pre[g][seg] : exclusive prefix over the frame's earlier segments; for instance
-//                     counters the frame-level list offset inst_off[m] is already added, so the
-//                     value is the list position where the segment's first entry of mask m goes
-//   frame_tot[f][c] : totals of the frame
-// and leaves seg_tab zeroed for the next call (it reads every entry anyway).
+// Cross-lane sums by DPP (no LDS, no ds_bpermute): quad swaps, half-row and row mirrors, then the two
+// row broadcasts -- six v_add_u32 with a DPP modifier; lanes 48..63 end up holding the wave total.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lpf_rl(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float lpf_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ unsigned long long lpf_rl64(unsigned long long v, int l)
+{
+    return (unsigned long long)lpf_rl((unsigned)v, l) | ((unsigned long long)lpf_rl((unsigned)(v >> 32), l) << 32);
+}
+#define LPF_DPP_ADD(x, ctrl, rows) ((x) + (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rows), 0xf, false))
+__device__ __forceinline__ unsigned lpf_wave_sum(unsigned x)           // sum over the 64 lanes, wave-uniform
+{
+    x = LPF_DPP_ADD(x, 0xB1, 0xf);       // quad_perm [1,0,3,2]
+    x = LPF_DPP_ADD(x, 0x4E, 0xf);       // quad_perm [2,3,0,1]
+    x = LPF_DPP_ADD(x, 0x141, 0xf);      // row_half_mirror
+    x = LPF_DPP_ADD(x, 0x140, 0xf);      // row_mirror: every lane of a row of 16 holds the row's sum
+    x = LPF_DPP_ADD(x, 0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    x = LPF_DPP_ADD(x, 0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+    return lpf_rl(x, 63);
+}
+__device__ __forceinline__ unsigned lpf_sum8(unsigned x)               // sum over lanes 0..7, wave-uniform
+{
+    x = LPF_DPP_ADD(x, 0xB1, 0xf);
+    x = LPF_DPP_ADD(x, 0x4E, 0xf);
+    x = LPF_DPP_ADD(x, 0x141, 0xf);
+    return lpf_rl(x, 0);
+}
+__device__ __forceinline__ unsigned lpf_wave_or(unsigned x)            // OR over the 64 lanes, wave-uniform
+{
+#define LPF_DPP_OR(x, ctrl, rows) ((x) | (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rows), 0xf, false))
+    x = LPF_DPP_OR(x, 0xB1, 0xf); x = LPF_DPP_OR(x, 0x4E, 0xf); x = LPF_DPP_OR(x, 0x141, 0xf); x = LPF_DPP_OR(x, 0x140, 0xf);
+    x = LPF_DPP_OR(x, 0x142, 0xa); x = LPF_DPP_OR(x, 0x143, 0xc);
+#undef LPF_DPP_OR
+    return lpf_rl(x, 63);
+}
+
+// ------------------------------------------------------------------------------------
+// SCAN (only for frames of more than 64 x 64 segments, whose prefixes one wave cannot derive from the group
+// table): one block per frame; turns the per-segment counters K1 accumulated into
+//   seg_pre[g][seg] : exclusive prefix over the frame's earlier segments; for instance counters the
+//                     frame-level list offset inst_off[m] is already added.
 // ------------------------------------------------------------------------------------
 // block-wide exclusive offsets of per-thread sums (4 components); also returns the totals
 __device__ __forceinline__ void lpf_block_excl4(const unsigned sum[4], unsigned excl[4], unsigned all[4],
@@ -377,62 +424,18 @@ __device__ __forceinline__ void lpf_block_excl4(const unsigned sum[4], unsigned 
     __syncthreads();
 }
 
-template <int NG>   // NG > 0: at most NG groups and 1024 segments -> everything stays in registers
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments_t(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments(const LpfParams P)
 {
-    // thread t owns the contiguous run of R = ceil(nseg/256) segments starting at t*R.
-    __shared__ unsigned s_toff[NG > 0 ? 1 : LPF_TAB_GROUPS][LPF_BLOCK][4];
+    // thread t owns the contiguous run of R = ceil(nseg/256) segments starting at t*R:
+    // phase 1 sums each run, phase 2 re-reads the runs (L2-hot) and writes the prefixes
+    __shared__ unsigned s_toff[LPF_TAB_GROUPS][LPF_BLOCK][4];
     __shared__ unsigned s_wsum[4][4], s_tot[LPF_TAB_ROWS], s_off[LPF_TAB_ROWS];
     const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
     const int seg_lo = fr.seg_off, seg_hi = fr.seg_off + fr.nseg;
     const int ngroups = (2 + P.M + 3) >> 2;
-    const int R = (NG > 0) ? 4 : (fr.nseg + LPF_BLOCK - 1) / LPF_BLOCK;
+    const int R = (fr.nseg + LPF_BLOCK - 1) / LPF_BLOCK;
     const int my_lo = min(seg_lo + tid * R, seg_hi), my_hi = min(my_lo + R, seg_hi);
-
-    if (NG > 0) {
-        // ---- one memory round trip: all runs of all groups are loaded before the first use ----
-        constexpr int G = NG > 0 ? NG : 1;
-        uint4 q[G][4];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                q[g][k] = (g < ngroups && my_lo + k < my_hi) ? P.seg_tab[(size_t)g * P.nseg_cap + my_lo + k] : make_uint4(0u, 0u, 0u, 0u);
-        unsigned excl[G][4];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const unsigned sum[4] = {q[g][0].x + q[g][1].x + q[g][2].x + q[g][3].x, q[g][0].y + q[g][1].y + q[g][2].y + q[g][3].y,
-                                     q[g][0].z + q[g][1].z + q[g][2].z + q[g][3].z, q[g][0].w + q[g][1].w + q[g][2].w + q[g][3].w};
-            unsigned all[4];
-            lpf_block_excl4(sum, excl[g], all, s_wsum, lane, wave);
-            if (tid == 0) { s_tot[4 * g] = all[0]; s_tot[4 * g + 1] = all[1]; s_tot[4 * g + 2] = all[2]; s_tot[4 * g + 3] = all[3]; }
-        }
-        __syncthreads();
-        if (tid < LPF_TAB_ROWS) {
-            const bool used = tid < 4 * ngroups;
-            unsigned off = 0;                              // inst_off[m] for the instance counters
-            if (used) for (int c = 2; c < tid; ++c) off += s_tot[c];
-            s_off[tid] = off;
-            P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = used ? s_tot[tid] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g >= ngroups) break;
-            unsigned run[4] = {s_off[4 * g] + excl[g][0], s_off[4 * g + 1] + excl[g][1], s_off[4 * g + 2] + excl[g][2], s_off[4 * g + 3] + excl[g][3]};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (my_lo + k < my_hi) {
-                    P.seg_pre[(size_t)g * P.nseg_cap + my_lo + k] = make_uint4(run[0], run[1], run[2], run[3]);
-                    P.seg_tab[(size_t)g * P.nseg_cap + my_lo + k] = make_uint4(0u, 0u, 0u, 0u);   // self-clean
-                }
-                run[0] += q[g][k].x; run[1] += q[g][k].y; run[2] += q[g][k].z; run[3] += q[g][k].w;
-            }
-        }
-        return;
-    }
-    // ---- general shape: phase 1 sums each run, phase 2 re-reads the runs (L2-hot) ------------
     for (int g = 0; g < ngroups; ++g) {
         const uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
         unsigned sum[4] = {0, 0, 0, 0};
@@ -444,57 +447,50 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments_t(const LpfParams
         unsigned excl[4], all[4];
         lpf_block_excl4(sum, excl, all, s_wsum, lane, wave);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s_toff[NG > 0 ? 0 : g][tid][j] = excl[j]; if (tid == 0) s_tot[4 * g + j] = all[j]; }
+        for (int j = 0; j < 4; ++j) { s_toff[g][tid][j] = excl[j]; if (tid == 0) s_tot[4 * g + j] = all[j]; }
     }
     __syncthreads();
     if (tid < LPF_TAB_ROWS) {
         const bool used = tid < 4 * ngroups;
-        unsigned off = 0;
+        unsigned off = 0;                                  // inst_off[m] for the instance counters
         if (used) for (int c = 2; c < tid; ++c) off += s_tot[c];
         s_off[tid] = off;
-        P.frame_tot[(size_t)f * LPF_TAB_ROWS + tid] = used ? s_tot[tid] : 0u;
     }
     __syncthreads();
     for (int g = 0; g < ngroups; ++g) {
-        uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
+        const uint4 *__restrict__ row = P.seg_tab + (size_t)g * P.nseg_cap;
         uint4 *__restrict__ pre = P.seg_pre + (size_t)g * P.nseg_cap;
         unsigned run[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) run[j] = s_off[4 * g + j] + s_toff[NG > 0 ? 0 : g][tid][j];
+        for (int j = 0; j < 4; ++j) run[j] = s_off[4 * g + j] + s_toff[g][tid][j];
 #pragma unroll 8
         for (int sg = my_lo; sg < my_hi; ++sg) {
             const uint4 v = row[sg];
             pre[sg] = make_uint4(run[0], run[1], run[2], run[3]);
-            row[sg] = make_uint4(0u, 0u, 0u, 0u);           // self-clean for the next call
             run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------
-// K2: one WAVE = one segment of LPF_SEG_QUANTUM (4096) points = 64 ballot rows, one per lane; four
-// independent waves per block, no block barriers.  Memory round trips on a wave's critical
-// path: {segment record, ballots, prefixes} -> {labels + xyz of the masked points, box
-// bounds} -> stores / atomics.
+// LISTS: one WAVE = one segment (seg_pts points = seg_pts/64 ballot rows, one per lane); four independent
+// waves per block, no block barriers.  From the ballots K1 left it writes the stable index lists:
+//   valid_idx (+ the compact uv_valid / label_valid)                                    (V3:585, 590-592)
+//   inst_idx, one list per mask                                                       (V3:225-228)
+//   mdense: the frame's masked points {x, y, z, label bits}, densely, in point order -- what the
+//           box-count kernel reads with every lane busy (K1 leaves them per wave, at that wave's slot).
+// Where a segment's entries start in its frame's lists is derived by the wave itself from the three
+// levels of counters K1's tiles added into (segment, group of 64 segments, frame): two masked wave sums
+// per counter, no scan kernel in between (PRE = true: frames with more than 64 groups, see lpf_scan_segments).
+// Memory round trips on a wave's critical path: {segment record, ballots, counters} -> {hand-off
+// entries of the masked points} -> stores.
 // ------------------------------------------------------------------------------------
-#define LPF_K2_ROWS (LPF_SEG_QUANTUM / 64)
-#define LPF_K2_WAVES 4
-#define LPF_K2_LDSCNT 256         // LDS inside-counters: M * B up to this many (else one global atomic per hit)
+#define LPF_LISTS_WAVES 4
+#define LPF_LIST_CAP 1024            // masked entries staged in LDS per pass (2 KB per wave)
 
-__device__ __forceinline__ unsigned lpf_rl(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ float lpf_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ unsigned long long lpf_rl64(unsigned long long v, int l)
-{
-    return (unsigned long long)lpf_rl((unsigned)v, l) | ((unsigned long long)lpf_rl((unsigned)(v >> 32), l) << 32);
-}
-// per-lane source lane (ds_bpermute): every lane is active at the call sites
-__device__ __forceinline__ unsigned long long lpf_rl64_var(unsigned long long v, int l)
-{
-    return (unsigned long long)(unsigned)__shfl((int)(unsigned)v, l) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(v >> 32), l) << 32);
-}
 
-// Set bits of 64 ballots (lane r holds row r, rowbase = bits set in earlier rows) -> ascending
-// list in LDS.  Every lane walks its own row: work is O(set bits), not O(rows x 64).
+// Set bits of the ballots of rows (lane r holds row r; rowbase = bits set in earlier rows of the pass) ->
+// ascending list in LDS.  Every lane walks its own row: work is O(set bits), not O(rows x 64).
 __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, unsigned rowbase, int lane, unsigned short *lst)
 {
     unsigned pos = rowbase;
@@ -506,373 +502,197 @@ __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, uns
     }
 }
 
-#define LPF_F2_LAB_NOVALID 1u
-#define LPF_F2_LAB_NOLIST 2u      // stop after valid_idx
-#define LPF_F2_LAB_NOBOX 4u
-#define LPF_F2_LAB_NOINST 8u
-#define LPF_F2_LAB_NOEXACT 16u
-#define LPF_F2_LAB_NOCAND 32u
-#define LPF_F2_LAB_NOPROJ 64u
-
-template <unsigned FL2>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k2_lists_t(const LpfParams P)
+template <bool PRE>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
 {
-#ifdef LPF_LAB_SMALL_LIDX
-    __shared__ unsigned short s_lidx[LPF_K2_WAVES][1024];   // LAB ONLY: sparse synthetic data
-#else
-    __shared__ unsigned short s_lidx[LPF_K2_WAVES][LPF_SEG_QUANTUM];   // valid, then masked points (segment-relative)
-#endif
-    __shared__ float4 s_pt[LPF_K2_WAVES][64];                          // xyz of the current 64 masked points
-    __shared__ float4 s_bq[LPF_K2_WAVES][2 * 64];                      // {lo, hi} of the current <= 64 boxes
-    __shared__ unsigned s_q[LPF_K2_WAVES][128];                        // (point, box) pairs that passed the float bounds
-    __shared__ unsigned s_cnt[LPF_K2_WAVES][LPF_K2_LDSCNT];            // this wave's inside counts [M][B] when they fit
+    __shared__ unsigned short s_lidx[LPF_LISTS_WAVES][LPF_LIST_CAP];
     const int lane = lpf_lane(), wave = lpf_wave();
-    const int sid = blockIdx.x * LPF_K2_WAVES + wave;
+    const int sid = blockIdx.x * LPF_LISTS_WAVES + wave;
     if (sid >= P.nseg_total) return;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // ---- round trip 1: everything that only depends on sid -------------------------------
     LpfFrame fr = P.frame0;
     if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];       // wave-uniform: scalar loads, one branch
     const int ngroups = (2 + P.M + 3) >> 2;
+    const int rps = P.seg_pts >> 6;                        // ballot rows per segment: 16 or 64
+    const int k = sid - fr.seg_off;                        // segment of its frame
     unsigned long long vb = 0, mb = 0;
-    uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
-    vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
-    mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
-    if (lane < ngroups) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
-
-    const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
-    const int seg_end = min(seg_start + LPF_SEG_QUANTUM, fr.N);
+    if (lane < rps) {
+        vb = P.vbal[(size_t)sid * rps + lane];
+        mb = P.mbal[(size_t)sid * rps + lane];
+    }
+    unsigned bef = 0, tot = 0;                             // lane c: entries of counter c before this segment / in the frame
+    if (PRE) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < ngroups) q = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
+        const int g = min(lane >> 2, LPF_TAB_GROUPS - 1);
+        const unsigned x = __shfl(q.x, g), y = __shfl(q.y, g), z = __shfl(q.z, g), w = __shfl(q.w, g);
+        bef = ((lane & 3) == 0) ? x : ((lane & 3) == 1) ? y : ((lane & 3) == 2) ? z : w;   // instance counters: inst_off[m] included
+    } else {
+        const int gi = k >> 6, j = k & 63;                 // group of 64 segments, place in it (gi < 64: host guarantees)
+        for (int g = 0; g < ngroups; ++g) {
+            uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, t = a;
+            if (lane < j) a = P.seg_tab[(size_t)g * P.nseg_cap + fr.seg_off + (gi << 6) + lane];
+            if (lane < gi) b = P.grp_tab[(size_t)g * P.ngrp_cap + fr.grp_off + lane];
+            if (lane < LPF_FRM_SHARDS) t = P.frm_tab[((size_t)fr.pad * LPF_FRM_SHARDS + lane) * LPF_TAB_GROUPS + g];
+            const unsigned px = lpf_wave_sum(a.x + b.x), py = lpf_wave_sum(a.y + b.y), pz = lpf_wave_sum(a.z + b.z), pw = lpf_wave_sum(a.w + b.w);
+            const unsigned tx = lpf_sum8(t.x), ty = lpf_sum8(t.y), tz = lpf_sum8(t.z), tw = lpf_sum8(t.w);
+            if ((lane >> 2) == g) {
+                bef = ((lane & 3) == 0) ? px : ((lane & 3) == 1) ? py : ((lane & 3) == 2) ? pz : pw;
+                tot = ((lane & 3) == 0) ? tx : ((lane & 3) == 1) ? ty : ((lane & 3) == 2) ? tz : tw;
+            }
+        }
+    }
+    const int seg_start = k * P.seg_pts;
+    const int seg_end = min(seg_start + P.seg_pts, fr.N);
     const int nrows = (seg_end - seg_start + 63) >> 6;
     if (lane >= nrows) { vb = 0; mb = 0; }                 // rows K1 never wrote
     const unsigned cv = __popcll(vb), cm = __popcll(mb);
     unsigned iv = cv, im = cm;
 #pragma unroll
-    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {            // inclusive scan over the 64 row counts
+    for (int o = 1; o < 64; o <<= 1) {                     // inclusive scan over the row counts
         const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
         if (lane >= o) { iv += tv; im += tm; }
     }
     const unsigned vbase = iv - cv, mbase = im - cm;
-    const unsigned nv = lpf_rl(iv, LPF_K2_ROWS - 1), L = lpf_rl(im, LPF_K2_ROWS - 1);
-    const long long run_v = (long long)lpf_rl(pre4.x, 0);
+    const unsigned nv = lpf_rl(iv, 63), L = lpf_rl(im, 63);
+    const long long run_v = (long long)lpf_rl(bef, 0);     // valid points of the frame before this segment
+    const unsigned run_m = lpf_rl(bef, 1);                 // masked points ...
 
-    // ---- valid_idx: ascending by construction (rows in order, lanes in order); staged in LDS so
-    //      the HBM writes are whole 512-byte runs instead of a few bytes per row ---------------
-    unsigned short *lst = s_lidx[wave];
-    if (P.valid_idx && nv && !(FL2 & LPF_F2_LAB_NOVALID)) {
-        lpf_bits_to_list(vb, vbase, lane, lst);
-        __builtin_amdgcn_wave_barrier();
+    // ---- valid_idx: ascending by construction.  Sparse segment: every lane walks the set bits of its own row
+    //      (as many steps as the fullest row has bits); dense one: row after row, a row's entries leave as one
+    //      contiguous run. ------------------------------------------------------------------------------------
+    if (P.valid_idx && nv) {
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
-        for (unsigned e = lane; e < nv; e += 64) dst[e] = (long long)(seg_start + (int)lst[e]);
-        if (P.uv_valid || P.label_valid) {                 // compact copies for callers that only read the valid points
-            const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
-            for (unsigned e = lane; e < nv; e += 64) {
-                const long long g = g0 + (int)lst[e];
-                if (P.uv_valid) P.uv_valid[o + e] = P.uv[g];
-                if (P.label_valid) P.label_valid[o + e] = P.label_bits[g];
+        const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        if (nv > 6u * (unsigned)nrows) {
+            for (int r = 0; r < nrows; ++r) {
+                const unsigned long long rv = lpf_rl64(vb, r);                      // wave-uniform
+                if ((rv >> lane) & 1ull) {
+                    const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+                    dst[pos] = (long long)(seg_start + r * 64 + lane);
+                    if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
+                    if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
+                }
+            }
+        } else {
+            unsigned long long bits = vb;
+            long long pos = vbase;
+            const int first = seg_start + lane * 64;
+            while (bits) {
+                const int pt = first + __ffsll((long long)bits) - 1;
+                bits &= bits - 1ull;
+                dst[pos] = (long long)pt;
+                if (P.uv_valid) P.uv_valid[o + pos] = P.uv[fr.pt_off + pt];
+                if (P.label_valid) P.label_valid[o + pos] = P.label_bits[fr.pt_off + pt];
+                ++pos;
             }
         }
-        __builtin_amdgcn_wave_barrier();                   // the list is reused for the masked points
     }
-    const int B = fr.B;
-    const bool do_inst = (P.inst_idx != nullptr) && !(FL2 & LPF_F2_LAB_NOINST);
-    const bool do_box = (B > 0) && (P.M > 0) && !(FL2 & LPF_F2_LAB_NOBOX);
-    if (L == 0 || !(do_inst || do_box) || (FL2 & LPF_F2_LAB_NOLIST)) return;
+    const bool do_inst = P.inst_idx != nullptr, do_dense = P.mdense != nullptr;
+    if (L == 0 || !(do_inst || do_dense)) return;
 
-    // ---- masked points of the segment -> this wave's LDS list, same stable order -----------
-    lpf_bits_to_list(mb, mbase, lane, lst);
-    __builtin_amdgcn_wave_barrier();                       // same wave, in-order LDS queue: reads below see the writes
-
-    // lane m keeps the next list position of mask m (the scan already added inst_off[m])
+    // lane m: where the next entry of mask m goes in the frame's concatenated lists
     unsigned posreg;
-    {
-        const int c = 2 + lane, g = min(c >> 2, LPF_TAB_GROUPS - 1);
-        const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
-        posreg = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
-    }
-    const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
-    const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-    // On a real scan the masked points of a segment sit mostly inside the same one or two boxes: one global
-    // atomic per hit piles thousands of adds onto a handful of L2 addresses (26 us of a 65 us kernel on sample
-    // frame 100).  Counts are gathered per wave in LDS (when M x B fits) and flushed once at the end.
-    const bool lds_cnt = do_box && (P.M * B <= LPF_K2_LDSCNT);
-    if (lds_cnt) {
-        for (int i = lane; i < P.M * B; i += 64) s_cnt[wave][i] = 0u;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
-    // the same order as the set bits of the masked ballots: entry e of the segment, found in
-    // row r, is entry e - mbase[first row of r's K1 wave] of that wave.  No gather from the cloud,
-    // the label array or (u, v).
-    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
-    const int rows_per_wave = P.tile_pts >> 8;              // K1 tile = 4 waves of tile_pts/4 points
-
-    for (unsigned e0 = 0; e0 < L; e0 += 64) {
-        // ---- round trip 2: the tile lists (coalesced) and the box bounds ---------------------
-        const unsigned e = e0 + lane;
-        const bool act = e < L;
-        float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-        const unsigned li = lst[act ? e : 0];                // segment-relative point index
-        const int first_row = ((int)(li >> 6) / rows_per_wave) * rows_per_wave;
-        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);            // all lanes take part
-        if (act) pq = mseg[first_row * 64 + (int)(e - wb)];
-        const unsigned idx = (unsigned)seg_start + li;
-        const unsigned lab = __float_as_uint(pq.w);
-        float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
-        if (do_box && lane < B) { blo = boxq[2 * lane]; bhi = boxq[2 * lane + 1]; }
-
-        // ---- K5: split by instance; ballot order == ascending point index --------------------
-        if (do_inst) {
-            for (int m = 0; m < P.M; ++m) {
-                const bool hit = (lab >> m) & 1u;
-                const unsigned long long bal = __ballot(hit);
-                if (!bal) continue;
-                const long long base = (long long)lpf_rl(posreg, m);
-                if (hit) {
-                    const long long w = base + __popcll(bal & lt);
-                    if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = (long long)idx;
-                }
-                if (lane == m) posreg += (unsigned)__popcll(bal);
-            }
-        }
-        // ---- K6: lane = masked point.  The frame's candidate grid (built with the boxes) lists, per
-        //      32x32-pixel cell, the boxes whose accepted region can project there; a point only
-        //      meets those.  Candidates pass a conservative float AABB of the region first, the
-        //      survivors are queued and take the reference's f64 test a whole wave at a time. ------
-        if (do_box) {
-            __builtin_amdgcn_wave_barrier();
-            s_pt[wave][lane] = make_float4(pq.x, pq.y, pq.z, __uint_as_float(lab));   // .w carries the label bits
-            s_bq[wave][2 * lane] = blo; s_bq[wave][2 * lane + 1] = bhi;               // bounds of boxes 0..63
-            __builtin_amdgcn_wave_barrier();
-            unsigned *qq = s_q[wave];
-            int qn = 0;                                     // wave-uniform queue length
-            auto exact = [&](int count) {
-                if (lane < count && !(FL2 & LPF_F2_LAB_NOEXACT)) {
-                    const unsigned ent = qq[lane];
-                    const int e = (int)(ent & 63u), b = (int)(ent >> 6);
-                    const float4 x = s_pt[wave][e];
-                    const double *bp = boxp + (size_t)b * 16;
-                    const bool in = P.oriented ? lpf_oriented_inside((double)x.x, (double)x.y, (double)x.z, bp)
-                                               : lpf_aabb_inside((double)x.x, (double)x.y, (double)x.z, bp);
-                    if (in) {
-                        unsigned l = __float_as_uint(x.w);
-                        while (l) {
-                            const int m = __ffs(l) - 1;
-                            l &= l - 1;
-                            if (lds_cnt) atomicAdd(&s_cnt[wave][m * B + b], 1u);
-                            else atomicAdd(&cnt[m * B + b], 1u);
-                        }
-                    }
-                }
-            };
-            int cell = 0;
-            if (act && !(FL2 & LPF_F2_LAB_NOPROJ)) {        // same arithmetic as K1 => the same pixel; valid => in range
-                double uf, vf, d;
-                lpf_project_point(P, pq.x, pq.y, pq.z, uf, vf, d);
-                cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
-            }
-            const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
-            for (int w = 0; w < fr.cand_words; ++w) {
-                unsigned long long mset = (act && !(FL2 & LPF_F2_LAB_NOCAND)) ? cg[w] : 0ull;
-                while (__any(mset != 0ull)) {
-                    const bool has = mset != 0ull;
-                    const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
-                    mset &= mset - 1ull;
-                    bool near = false;
-                    if (has) {
-                        float4 lo, hi;
-                        if (b < 64) { lo = s_bq[wave][2 * b]; hi = s_bq[wave][2 * b + 1]; }
-                        else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
-                        near = pq.x >= lo.x && pq.x <= hi.x && pq.y >= lo.y && pq.y <= hi.y && pq.z >= lo.z && pq.z <= hi.z;
-                    }
-                    const unsigned long long bal = __ballot(near);
-                    if (!bal) continue;
-                    if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
-                    qn += __popcll(bal);
-                    if (qn >= 64) {
-                        __builtin_amdgcn_wave_barrier();
-                        exact(64);
-                        const unsigned t = qq[64 + lane];
-                        __builtin_amdgcn_wave_barrier();
-                        qq[lane] = t;
-                        qn -= 64;
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            exact(qn);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (lds_cnt) {
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < P.M * B; i += 64) {
-            const unsigned v = s_cnt[wave][i];
-            if (v) atomicAdd(&cnt[i], v);
-        }
-    }
-}
-
-#define lpf_k2_lists lpf_k2_lists_t<0u>
-
-// Small frames (<= 64 segments, lane = segment) need no scan kernel: a wave derives, from the frame's rows of
-// seg_tab, for counter c = lane: bef = sum over the frame's segments before segment k, tot = sum over all of them.
-__device__ __forceinline__ void lpf_wave_frame_counts(const LpfParams &P, const LpfFrame &fr, int k, int lane, unsigned &bef, unsigned &tot)
-{
-    const int ngroups = (2 + P.M + 3) >> 2;
-    bef = 0u; tot = 0u;
-    for (int g = 0; g < ngroups; ++g) {
-        uint4 t = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < fr.nseg) t = P.seg_tab[(size_t)g * P.nseg_cap + fr.seg_off + lane];
-        unsigned x[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {              // inclusive scan over the segments
-                const unsigned u = __shfl_up(x[j], o);
-                if (lane >= o) x[j] += u;
-            }
-            const unsigned b = (k > 0) ? lpf_rl(x[j], k - 1) : 0u, a = lpf_rl(x[j], 63);
-            if (lane == 4 * g + j) { bef = b; tot = a; }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// K2, one BLOCK per segment: same results as lpf_k2_lists_t, for launches that leave most of the chip idle
-// (a single frame, a few real frames).  There a wave has its SIMD to itself and runs at one instruction every
-// ~6 cycles, and real scans are dense in places -- consecutive points are neighbours in space, so a segment
-// lying on cars holds over a thousand valid and hundreds of masked points: the per-segment wave of the
-// throughput form becomes a 40 us serial program (measured on sample frame 100: list building 20 k cycles,
-// 8 chunks x 9 k cycles of instance split + candidate walk + exact test).  Here the NW (4 or 8) waves of a block share
-// one segment: rows are split NW ways for the lists (written row-parallel: a row's valid points go out as
-// one contiguous run, no LDS staging), chunks of 64 masked points are dealt round-robin to the waves, and the
-// order-dependent part -- where in the instance lists a chunk's points go -- comes from a per-(chunk, mask)
-// count table in LDS, so nothing is serial across chunks.
-// ------------------------------------------------------------------------------------
-#define LPF_K2B_LDSB 32           // boxes whose exact parameters the block keeps in LDS
-
-template <int NW>   // waves per segment: 4 or 8
-__global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
-{
-    __shared__ unsigned short s_list[LPF_SEG_QUANTUM];                 // masked points, segment-relative, stable order
-    __shared__ unsigned short s_cc[LPF_K2_ROWS][LPF_MAX_MASKS_DEV];    // [chunk][mask] -> entries of that mask in the chunk
-    __shared__ float4 s_pt[NW][64];                          // xyz + label of a wave's current chunk
-    __shared__ unsigned s_q[NW][128];                        // (point, box) pairs that passed the float bounds
-    __shared__ float4 s_bq[2 * 64];                                    // {lo, hi} float bounds of boxes 0..63
-    __shared__ double s_bp[LPF_K2B_LDSB * 16];                         // exact parameters of boxes 0..LPF_K2B_LDSB-1
-    __shared__ unsigned s_cnt[LPF_K2_LDSCNT];                          // inside counts [M][B] when they fit
-    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const int sid = blockIdx.x;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    // ---- round trip 1 (every wave, redundantly: it is 1 KB and the scan is 60 instructions) -------------
-    LpfFrame fr = P.frame0;
-    if (P.F > 1) fr = P.segs[sid];
-    const int ngroups = (2 + P.M + 3) >> 2;
-    unsigned long long vb = P.vbal[(size_t)sid * LPF_K2_ROWS + lane];
-    unsigned long long mb = P.mbal[(size_t)sid * LPF_K2_ROWS + lane];
-    uint4 pre4 = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < ngroups && !P.inline_scan) pre4 = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
-    const int seg_start = (sid - fr.seg_off) * LPF_SEG_QUANTUM;
-    const int seg_end = min(seg_start + LPF_SEG_QUANTUM, fr.N);
-    const int nrows = (seg_end - seg_start + 63) >> 6;
-    if (lane >= nrows) { vb = 0; mb = 0; }
-    const unsigned cv = __popcll(vb), cm = __popcll(mb);
-    unsigned iv = cv, im = cm;
-#pragma unroll
-    for (int o = 1; o < LPF_K2_ROWS; o <<= 1) {
-        const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
-        if (lane >= o) { iv += tv; im += tm; }
-    }
-    const unsigned vbase = iv - cv, mbase = im - cm;
-    const unsigned L = lpf_rl(im, LPF_K2_ROWS - 1);
-    long long run_v = (long long)lpf_rl(pre4.x, 0);
-    unsigned segpos_inline = 0u;                            // lane m: list position of mask m at the start of the segment
-    if (P.inline_scan) {
-        unsigned bef, tot;
-        lpf_wave_frame_counts(P, fr, sid - fr.seg_off, lane, bef, tot);
-        run_v = (long long)lpf_rl(bef, 0);
-        unsigned off = (lane >= 2 && lane < 2 + P.M) ? tot : 0u;     // inst_off[m] = totals of the masks before m
+    if (PRE) {
+        posreg = (unsigned)__shfl((int)bef, (lane + 2) & 63);
+    } else {
+        unsigned off = (lane >= 2 && lane < 2 + P.M) ? tot : 0u;      // inst_off[m] = totals of the masks before m
         const unsigned own = off;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned u = __shfl_up(off, o);
             if (lane >= o) off += u;
         }
-        segpos_inline = (unsigned)__shfl((int)(off - own + bef), (lane + 2) & 63);
+        posreg = (unsigned)__shfl((int)(off - own + bef), (lane + 2) & 63);
     }
-    const int B = fr.B;
-    const bool do_inst = P.inst_idx != nullptr;
-    const bool do_box = (B > 0) && (P.M > 0);
-    const bool masked_part = (L != 0) && (do_inst || do_box);   // block-uniform
+    // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
+    // the same order as the set bits of the masked ballots: entry e of the segment, found in
+    // row r, is entry e - mbase[first row of r's K1 wave] of that wave.
+    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+    const int rows_per_wave = P.tile_pts >> 8;             // K1 tile = 4 waves of tile_pts/4 points
+    const int rpw_shift = (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
+    float4 *__restrict__ dense = do_dense ? P.mdense + fr.pt_off + run_m : nullptr;
+    unsigned short *lst = s_lidx[wave];
+
+    for (int r0 = 0; r0 < nrows;) {                        // passes of at most LPF_LIST_CAP entries (one, except on very dense segments)
+        const unsigned start = lpf_rl(mbase, r0);
+        const unsigned long long fit = __ballot(lane >= r0 && lane < nrows && (im - start) <= (unsigned)LPF_LIST_CAP);
+        const int r1 = r0 + max(__popcll(fit), 1);         // rows [r0, r1): im is non-decreasing, so the fitting rows are a run
+        const unsigned cnt = lpf_rl(im, r1 - 1) - start;
+        if (cnt) {
+            if (lane >= r0 && lane < r1) lpf_bits_to_list(mb, mbase - start, lane, lst);
+            __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: reads below see the writes
+            for (unsigned e0 = 0; e0 < cnt; e0 += 64) {
+                const unsigned e = e0 + lane;
+                const bool act = e < cnt;
+                const unsigned li = lst[act ? e : 0];      // segment-relative point index
+                const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
+                const unsigned wb = (unsigned)__shfl((int)mbase, first_row);            // all lanes take part
+                float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act) pq = mseg[first_row * 64 + (int)(start + e - wb)];
+                const unsigned lab = __float_as_uint(pq.w);
+                if (dense && act) dense[start + e] = pq;   // 1 KiB contiguous per chunk
+                if (do_inst) {                             // split by instance; ballot order == ascending point index
+                    const long long idx = (long long)(seg_start + (int)li);
+                    unsigned any = lpf_wave_or(lab);
+                    while (any) {
+                        const int m = __ffs(any) - 1;
+                        any &= any - 1u;
+                        const bool hit = (lab >> m) & 1u;
+                        const unsigned long long bal = __ballot(hit);
+                        const long long base = (long long)lpf_rl(posreg, m);
+                        if (hit) {
+                            const long long w = base + __popcll(bal & lt);
+                            if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = idx;
+                        }
+                        if (lane == m) posreg += (unsigned)__popcll(bal);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // the list is rewritten by the next pass
+        }
+        r0 = r1;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BOX COUNT: count_mb[m][b] = number of points of mask m inside box b (V3:344-376: np.sum(oriented_point_in_bbox(...))).
+// Grid (slices, frames): the blocks of a frame share its dense masked-point list in chunks of 256 (lane = masked point,
+// every lane busy whatever the scan order did to the segments).  The frame's candidate grid (built with the boxes)
+// lists, per 32x32-pixel cell, the boxes whose accepted region can project there; a point only meets those.
+// Candidates pass a conservative float AABB of the region first, the survivors are queued per wave and take the
+// reference's f64 test a whole wave at a time.  Hits are counted in LDS and flushed once per block.
+// ------------------------------------------------------------------------------------
+#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS
+#define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_boxcount(const LpfParams P)
+{
+    __shared__ float4 s_pt[4][64];                          // xyz + label of a wave's current chunk
+    __shared__ unsigned s_q[4][128];                        // (point, box) pairs that passed the float bounds
+    __shared__ float4 s_bq[2 * 64];                         // {lo, hi} float bounds of boxes 0..63
+    __shared__ double s_bp[LPF_BC_LDSB * 16];               // exact parameters of boxes 0..LPF_BC_LDSB-1
+    __shared__ unsigned s_cnt[LPF_BC_LDSCNT];
+    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
+    const int f = blockIdx.y;
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const int B = fr.B, M = P.M;
+    unsigned t = 0;
+    if (lane < LPF_FRM_SHARDS) t = P.frm_tab[((size_t)f * LPF_FRM_SHARDS + lane) * LPF_TAB_GROUPS].y;   // counter 1: masked points
+    const unsigned L = lpf_sum8(t);                        // block-uniform
+    if (L == 0 || B == 0 || M == 0 || (unsigned)blockIdx.x * LPF_BLOCK >= L) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-    const bool lds_cnt = do_box && (P.M * B <= LPF_K2_LDSCNT);
-
-    // box data of the frame -> LDS, loads issued before the list work (one round trip for the block)
-    if (masked_part && do_box) {
-        if (tid < 2 * min(B, 64)) s_bq[tid] = boxq[tid];
-        for (int i = tid; i < min(B, LPF_K2B_LDSB) * 16; i += NW * 64) s_bp[i] = boxp[i];
-        if (lds_cnt) for (int i = tid; i < P.M * B; i += NW * 64) s_cnt[i] = 0u;
-    }
-    // ---- lists, row-parallel: wave w owns 64/NW consecutive rows; lane = point of the row ---------------
-    {
-        long long *__restrict__ dst = P.valid_idx ? P.valid_idx + fr.pt_off + run_v : nullptr;
-        for (int r = wave * (64 / NW); r < (wave + 1) * (64 / NW); ++r) {
-            const unsigned long long rv = lpf_rl64(vb, r), rm = lpf_rl64(mb, r);     // wave-uniform
-            if (dst && ((rv >> lane) & 1ull)) {                                      // contiguous run of popc(rv) entries
-                const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt), g = fr.pt_off + seg_start + r * 64 + lane;
-                dst[pos] = (long long)(seg_start + r * 64 + lane);
-                if (P.uv_valid) P.uv_valid[fr.pt_off + run_v + pos] = P.uv[g];
-                if (P.label_valid) P.label_valid[fr.pt_off + run_v + pos] = P.label_bits[g];
-            }
-            if (masked_part && ((rm >> lane) & 1ull))
-                s_list[lpf_rl(mbase, r) + __popcll(rm & lt)] = (unsigned short)(r * 64 + lane);
-        }
-    }
-    if (!masked_part) return;                               // block-uniform: no barrier is skipped by part of a block
+    unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
+    const bool lds_cnt = M * B <= LPF_BC_LDSCNT;
+    if (tid < 2 * min(B, 64)) s_bq[tid] = boxq[tid];
+    for (int i = tid; i < min(B, LPF_BC_LDSB) * 16; i += LPF_BLOCK) s_bp[i] = boxp[i];
+    if (lds_cnt) for (int i = tid; i < M * B; i += LPF_BLOCK) s_cnt[i] = 0u;
     __syncthreads();
 
-    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;     // K1's hand-off lists (see lpf_k2_lists_t)
-    const int rows_per_wave = P.tile_pts >> 8;
-    const int rpw_shift = (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
-    const int nchunks = (int)((L + 63u) >> 6);
-    auto load_chunk = [&](int c, unsigned &li) -> float4 {  // entry c*64+lane of the segment's masked points (clamped, branch-free)
-        const unsigned e = (unsigned)c * 64u + lane;
-        const bool act = e < L;
-        li = s_list[act ? e : 0];
-        const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
-        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
-        return mseg[act ? first_row * 64 + (int)(e - wb) : 0];
-    };
-    // ---- pass A: per-(chunk, mask) counts; chunks dealt round-robin, the first two kept in registers --------
-    float4 keep_p[2];
-    unsigned keep_li[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { keep_p[k] = make_float4(0.f, 0.f, 0.f, 0.f); keep_li[k] = 0u; }
-    if (do_inst) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = wave + NW * k;
-            if (c < nchunks) keep_p[k] = load_chunk(c, keep_li[k]);
-        }
-        for (int c = wave, k = 0; c < nchunks; c += NW, ++k) {
-            unsigned li;
-            const float4 p = (k == 0) ? keep_p[0] : (k == 1) ? keep_p[1] : load_chunk(c, li);
-            const unsigned lab = ((unsigned)c * 64u + lane < L) ? __float_as_uint(p.w) : 0u;
-            unsigned mine = 0u;
-            for (int m = 0; m < P.M; ++m) {
-                const unsigned n = (unsigned)__popcll(__ballot((lab >> m) & 1u));
-                if (lane == m) mine = n;
-            }
-            if (lane < LPF_MAX_MASKS_DEV) s_cc[c][lane] = (unsigned short)mine;
-        }
-    }
-    __syncthreads();
-
-    // ---- pass B: instance lists + box counts of the wave's chunks ------------------------------------------
+    const float4 *__restrict__ dense = P.mdense + fr.pt_off;
     unsigned *qq = s_q[wave];
     auto exact = [&](int count) {
         if (lane < count) {
@@ -880,14 +700,8 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
             const int e = (int)(ent & 63u), b = (int)(ent >> 6);
             const float4 x = s_pt[wave][e];
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
-            bool in;
-            if (b < LPF_K2B_LDSB) {
-                const double *bp = s_bp + b * 16;
-                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            } else {
-                const double *bp = boxp + (size_t)b * 16;
-                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            }
+            const double *bp = (b < LPF_BC_LDSB) ? s_bp + b * 16 : boxp + (size_t)b * 16;
+            const bool in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
             if (in) {
                 unsigned l = __float_as_uint(x.w);
                 while (l) {
@@ -899,47 +713,16 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
             }
         }
     };
-    // lane m: list position of mask m at the start of the segment (the scan already added inst_off[m])
-    unsigned segpos;
-    {
-        const int c = 2 + lane, g = min(c >> 2, LPF_TAB_GROUPS - 1);
-        const unsigned x = __shfl(pre4.x, g), y = __shfl(pre4.y, g), z = __shfl(pre4.z, g), w = __shfl(pre4.w, g);
-        segpos = ((c & 3) == 0) ? x : ((c & 3) == 1) ? y : ((c & 3) == 2) ? z : w;
-        if (P.inline_scan) segpos = segpos_inline;
-    }
-    unsigned before = 0u;                                   // lane m: entries of mask m in chunks [0, c) -- advanced incrementally
-    int counted = 0;
-    for (int c = wave, k = 0; c < nchunks; c += NW, ++k) {
-        unsigned li = (k == 0) ? keep_li[0] : keep_li[1];
-        const bool kept = do_inst && k < 2;
-        const float4 p = kept ? ((k == 0) ? keep_p[0] : keep_p[1]) : load_chunk(c, li);
-        const int nact = (int)min(64u, L - (unsigned)c * 64u);
-        const bool act = lane < nact;
-        const unsigned idx = (unsigned)seg_start + li;
-        const unsigned lab = act ? __float_as_uint(p.w) : 0u;
-        if (do_inst) {
-            if (lane < LPF_MAX_MASKS_DEV)
-                for (; counted < c; ++counted) before += s_cc[counted][lane];
-            counted = c;
-            const unsigned posreg = segpos + before;
-            for (int m = 0; m < P.M; ++m) {
-                const bool hit = (lab >> m) & 1u;
-                const unsigned long long bal = __ballot(hit);
-                if (!bal) continue;
-                const long long base = (long long)lpf_rl(posreg, m);
-                if (hit) {
-                    const long long w = base + __popcll(bal & lt);
-                    if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = (long long)idx;
-                }
-            }
-        }
-        if (!do_box) continue;
+    for (unsigned c0 = (unsigned)blockIdx.x * LPF_BLOCK; c0 < L; c0 += gridDim.x * LPF_BLOCK) {   // block-uniform
+        const unsigned e = c0 + tid;
+        const bool act = e < L;
+        const float4 p = dense[act ? e : c0];
         __builtin_amdgcn_wave_barrier();
-        s_pt[wave][lane] = make_float4(p.x, p.y, p.z, __uint_as_float(lab));   // .w carries the label bits
+        s_pt[wave][lane] = act ? p : make_float4(0.f, 0.f, 0.f, 0.f);      // .w carries the label bits
         __builtin_amdgcn_wave_barrier();
-        int qn = 0;
+        int qn = 0;                                         // wave-uniform queue length
         int cell = 0;
-        if (act) {                                          // same arithmetic as K1 => the same pixel; valid => in range
+        if (act) {                                          // same arithmetic as K1 => the same pixel; masked => valid => in range
             double uf, vf, d;
             lpf_project_point(P, p.x, p.y, p.z, uf, vf, d);
             cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
@@ -965,9 +748,9 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
                 if (qn >= 64) {
                     __builtin_amdgcn_wave_barrier();
                     exact(64);
-                    const unsigned t = qq[64 + lane];
+                    const unsigned rest = qq[64 + lane];
                     __builtin_amdgcn_wave_barrier();
-                    qq[lane] = t;
+                    qq[lane] = rest;
                     qn -= 64;
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -979,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void lpf_k2_block(const LpfParams P)
     }
     if (lds_cnt) {
         __syncthreads();
-        for (int i = tid; i < P.M * B; i += NW * 64) {
+        for (int i = tid; i < M * B; i += LPF_BLOCK) {
             const unsigned v = s_cnt[i];
             if (v) atomicAdd(&cnt[i], v);
         }
@@ -1002,18 +785,24 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
     long long *w = (long long *)base;
     int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
     __shared__ unsigned s_tot[LPF_TAB_ROWS];
-    const unsigned *__restrict__ tot = P.frame_tot + (size_t)f * LPF_TAB_ROWS;
-    if (P.inline_scan) {                                    // block-uniform: the frame's totals, then seg_tab is handed back clean
-        if (tid < 64) {
-            unsigned bef, all;
-            lpf_wave_frame_counts(P, fr, 0, lane, bef, all);
-            if (lane < LPF_TAB_ROWS) s_tot[lane] = (lane < 2 + M) ? all : 0u;
-        }
-        __syncthreads();
-        tot = s_tot;
-        const int ngroups = (2 + M + 3) >> 2;
-        for (int i = tid; i < ngroups * fr.nseg; i += LPF_BLOCK)
-            P.seg_tab[(size_t)(i / fr.nseg) * P.nseg_cap + fr.seg_off + (i % fr.nseg)] = make_uint4(0u, 0u, 0u, 0u);
+    // the frame's totals: sum of the 8 shards K1's tiles added into; then the three counter levels are handed back
+    // zeroed for the next run (this kernel is the last reader)
+    const int ngroups = (2 + M + 3) >> 2;
+    if (tid < LPF_TAB_ROWS) {
+        unsigned a = 0;
+        if (tid < 4 * ngroups)
+            for (int sh = 0; sh < LPF_FRM_SHARDS; ++sh)
+                a += reinterpret_cast<const unsigned *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + sh) * LPF_TAB_GROUPS)[tid];
+        s_tot[tid] = (tid < 2 + M) ? a : 0u;
+    }
+    __syncthreads();
+    const unsigned *__restrict__ tot = s_tot;
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
+        for (int i = tid; i < ngroups * fr.nseg; i += LPF_BLOCK) P.seg_tab[(size_t)(i / fr.nseg) * P.nseg_cap + fr.seg_off + (i % fr.nseg)] = z;
+        for (int i = tid; i < ngroups * ngrp; i += LPF_BLOCK) P.grp_tab[(size_t)(i / ngrp) * P.ngrp_cap + fr.grp_off + (i % ngrp)] = z;
+        for (int i = tid; i < LPF_FRM_SHARDS * LPF_TAB_GROUPS; i += LPF_BLOCK) P.frm_tab[(size_t)f * LPF_FRM_SHARDS * LPF_TAB_GROUPS + i] = z;
     }
 
     // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes

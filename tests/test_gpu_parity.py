@@ -18,12 +18,13 @@ I32 = np.iinfo(np.int32)
 TOL = 1e-5
 
 
-@pytest.fixture(scope="module", params=["block", "wave"])
+@pytest.fixture(scope="module", params=["small", "large", "large-scan"])
 def ctx(request):
-    """Every parity test runs against both forms of the list/box-count kernel (lpf_set_list_kernel)."""
+    """Every parity test runs under each launch geometry (lpf_set_geometry): 1024-point segments, 4096-point segments, and
+    4096-point segments with the prefixes from the scan kernel (the path of frames beyond 16.7 M points)."""
     from lidar_object_detection_amd._native import LpfContext
     c = LpfContext(0)
-    c.set_list_kernel(request.param)
+    c.set_geometry(request.param)
     yield c
     c.close()
 

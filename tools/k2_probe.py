@@ -33,12 +33,12 @@ def main():
                  valid_idx=torch.empty(F * n, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, n), dtype=torch.int64, device=dev),
                  count_mb=torch.zeros(F * M * B, dtype=torch.int32, device=dev),
                  summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
-        for form in ("wave", "block"):
+        for form in ("small", "large"):
             ctx = LpfContext(0)
             ctx.set_stream(stream.cuda_stream)
             ctx.set_camera(T, K3, W, H, 0.0, 50.0)
             ctx.set_boxes([corners] * F)
-            ctx.set_list_kernel(form)
+            ctx.set_geometry(form)
             step = ctx.make_device_step(d_pts, off, masks_u8=d_masks, erode_iters=0, inst_cap=n, **o)
             for _ in range(20):
                 step()
