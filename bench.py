@@ -158,6 +158,8 @@ MODES = {
     "pipeline": (True, False, 0, "tail kernels (scan, lists, finalize) of step i on a second stream, overlapping step i+1"),
     "pipeline-pack": (True, True, 0, "pipeline + the mask pack of step i+1 on a third stream"),
     "partition": (True, True, 32, "pipeline-pack with both side streams confined to 32 CUs (4 per XCD)"),
+    "fused": ("fused", False, 0, "software pipelining in one launch per step: the tail of step i-1 and the summaries of step i-2 "
+                                 "ride among the streaming tiles of step i"),
 }
 DEFAULT_MODE = "serial"
 
@@ -371,6 +373,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip the second, event-bracketed pass")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (N = 1 only anyway)")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command of --gpus N and exit (tests)")
+    ap.add_argument("--lab", default="", help="diagnosis only (no oracle check, never a reported number): 'nolists', 'noboxes' or 'nomasks'")
     args = ap.parse_args()
     if args.pipeline:
         args.mode = "pipeline"
@@ -444,13 +447,19 @@ def main():
             c.set_cu_partition(side_cus, exclusive=args.exclusive)
         c.set_pipelined(pipelined, pack_side=pack_side)
         c.set_camera(T, K, W, H, 0.0, DMAX)
-        c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
+        if args.lab != "noboxes":
+            c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
         c.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctxs.append(c)
     ctx = ctxs[0]
 
     # one step = K8 mask pack (u8 masks in HBM -> label images) + K1 + scan + K2 + K3, pre-marshalled
-    steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=masks_dev[b], inst_cap=n, **outs[b])
+    if args.lab == "nolists":
+        for o in outs:
+            o["valid_idx"] = None
+            o["inst_idx"] = None
+    steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b],
+                                                   inst_cap=n, **outs[b])
                 for b in range(nbuf)]
 
     def barrier():
@@ -495,7 +504,7 @@ def main():
             c.profile_enable(False)
 
     # the numbers are only reported if the last step's results equal the CPU oracle's (frame 0, rank 0)
-    if rank == 0:
+    if rank == 0 and not args.lab:
         from oracle import cpu_oracle as orc
         b = (args.steps - 1) % nbuf
         sm = np.frombuffer(outs[b]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
@@ -556,6 +565,8 @@ def main():
                                        "kernel itself lies between avg_us - empty_bracket_us and avg_us (rocprofv3's average of "
                                        "the same command, profiles/, falls inside that interval)"
                                        % (args.steps, 1e3 * elapsed_ev / args.steps)}
+        if args.lab:
+            line["metric"] = "LAB RUN (%s): not a benchmark result" % args.lab
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(scenes[0], T, K, W, H, args.cpu_seconds)
         if world == 1 and not args.no_secondary:

@@ -107,13 +107,19 @@ int  lpf_use_own_stream(lpf_ctx *ctx);
 int  lpf_wait_for_stream(lpf_ctx *ctx, void *producer_stream);
 int  lpf_release_to_stream(lpf_ctx *ctx, void *consumer_stream);
 int  lpf_sync(lpf_ctx *ctx);
-/* Pipelined device-mode runs.  on = 1: the short tail kernels of a run (segment scan, list building,
+/* Pipelined device-mode runs.  on = 2 (the fast one): software pipelining inside ONE launch per run -- the launch
+ * of run i carries its own streaming kernel, the tail (index lists, box counts) of run i-1 dealt out among the
+ * streaming tiles, and the per-frame summaries of run i-2; three scratch sets rotate, nothing in a launch depends on
+ * anything else in it, no second stream and no event is involved.  What is still owed is launched by lpf_sync(),
+ * lpf_release_to_stream() or any call that changes the context's state.
+ * on = 1: the short tail kernels of a run (index lists, box counts,
  * per-frame summary) execute on a second, internal stream and overlap the streaming kernel of
  * the next run, which uses a second set of scratch buffers.  on = 3: in addition device-mode
  * lpf_set_masks_* pack on a third internal stream, into the label images of the NEXT run, so the pack overlaps
  * the streaming kernel already queued; the mask tensor must then be complete when lpf_set_masks_* is
- * called (the side stream does not wait for the caller's stream).  With either on, the outputs of a run are
- * complete after lpf_sync(), not after the caller's stream alone.  0 = off (default). */
+ * called (the side stream does not wait for the caller's stream).  With any of them on, the outputs of a run are
+ * complete after lpf_sync() (or lpf_release_to_stream()), not after the caller's stream alone, and the caller's
+ * output buffers of a run must stay untouched until then.  0 = off (default). */
 int  lpf_set_pipelined(lpf_ctx *ctx, int on);
 /* Confine the internal side streams of the pipelined mode to side_cus compute units (a multiple of 8: the same
  * share of each of the 8 XCDs; 0 = no confinement), so the tail kernels do not take issue slots from the

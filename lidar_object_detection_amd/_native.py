@@ -277,10 +277,12 @@ class LpfContext:
         self._check(self._lib.lpf_sync(self._h))
 
     def set_pipelined(self, on=True, pack_side=False):
-        """Tail kernels of a device-mode run on a second stream (overlap with the next run); with pack_side the
+        """Pipelined device-mode runs (lpf_set_pipelined).  ``on="fused"``: the tail of a run rides in the next run's launch
+        (one launch per run, no second stream).  ``on=True``: tail kernels on a second stream; with pack_side the
         device-mode mask packing too (third stream; the masks must be complete when set_masks is called).
-        Results of a run are then complete after sync()."""
-        self._check(self._lib.lpf_set_pipelined(self._h, (3 if pack_side else 1) if on else 0))
+        Results of a run are complete after sync() / release_to_stream()."""
+        mode = 2 if on == "fused" else ((3 if pack_side else 1) if on else 0)
+        self._check(self._lib.lpf_set_pipelined(self._h, mode))
 
     def set_cu_partition(self, side_cus=0, exclusive=False):
         """Confine the side streams of the pipelined mode to ``side_cus`` CUs (multiple of 8); with ``exclusive`` the

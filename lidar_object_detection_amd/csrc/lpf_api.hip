@@ -67,18 +67,27 @@ struct lpf_ctx {
     bool cand_dirty = true;
 
     // per-run scratch
-    DevBuf frames, segs;
+    DevBuf frames, segs, blks;
     // Scratch of one in-flight run.  Two sets: with pipelining on, the tail kernels of run i (second
     // stream) overlap the streaming kernel of run i+1 (caller's stream), which uses the other set.
     struct Scratch {
-        DevBuf vbal, mbal, seg_tab, grp_tab, frm_tab, seg_pre, cnt, mlist, mdense;
+        DevBuf vbal, mbal, seg_tab, grp_tab, frm_tab, seg_pre, cnt, mlist;
         DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
         void *label_cur = nullptr;
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
         hipEvent_t k1_done = nullptr, tail_done = nullptr, mask_done = nullptr;
         bool tail_pending = false, k1_recorded = false, mask_pending = false;
-    } sc[2];
+    } sc[3];
     int parity = 0;
+    // Software-pipelined mode (lpf_set_pipelined 2): what earlier runs still owe.  The tail of the last run and the
+    // summaries of the one before ride in the next run's launch (lpf_step_t) or are flushed by flush_pending().
+    struct Pending {
+        bool valid = false;
+        LpfParams P;
+        bool pre = false;                 // its prefixes come from the scan kernel
+        int ntail = 0;                    // tail blocks
+    } pend_tail, pend_fin;
+    bool fused = false;
     int geometry = 0;                 // lpf_set_geometry: 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes
     bool pipelined = false;
     bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
@@ -92,6 +101,7 @@ struct lpf_ctx {
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
     std::vector<LpfFrame> h_segs;
+    std::vector<int2> h_blks;         // tail block table (see lpf_tail_t)
 
     // optional event bracketing of K1 (lpf_profile_*)
     bool profiling = false;
@@ -128,8 +138,31 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                     \
     } while (0)
 
-int sync_all(lpf_ctx *c)                // both streams idle: shared tables / buffers may be rewritten
+// software-pipelined mode: launch what earlier runs still owe, on the context's stream
+int flush_pending(lpf_ctx *c)
 {
+    if (c->pend_fin.valid) {
+        hipLaunchKernelGGL(lpf_finalize, dim3(c->pend_fin.P.F), dim3(LPF_BLOCK), 0, c->stream, c->pend_fin.P);
+        LPF_HIP(c, hipGetLastError());
+        c->pend_fin.valid = false;
+    }
+    if (c->pend_tail.valid) {
+        const lpf_ctx::Pending &T = c->pend_tail;
+        if (T.ntail > 0) {
+            if (T.pre) hipLaunchKernelGGL((lpf_tail_t<true>), dim3(T.ntail), dim3(LPF_BLOCK), 0, c->stream, T.P);
+            else hipLaunchKernelGGL((lpf_tail_t<false>), dim3(T.ntail), dim3(LPF_BLOCK), 0, c->stream, T.P);
+            LPF_HIP(c, hipGetLastError());
+        }
+        hipLaunchKernelGGL(lpf_finalize, dim3(T.P.F), dim3(LPF_BLOCK), 0, c->stream, T.P);
+        LPF_HIP(c, hipGetLastError());
+        c->pend_tail.valid = false;
+    }
+    return LPF_OK;
+}
+
+int sync_all(lpf_ctx *c)                // every stream idle, nothing owed: shared tables / buffers may be rewritten
+{
+    if (!c->capturing && (c->pend_tail.valid || c->pend_fin.valid)) { int rc_ = flush_pending(c); if (rc_) return rc_; }
     if (c->capturing)
         return fail(c, LPF_ERR_STATE, "this call needs a synchronisation or (re)allocation, which cannot be captured into a graph: "
                                       "run the same shapes once before lpf_graph_begin");
@@ -446,7 +479,7 @@ void lpf_destroy(lpf_ctx *c)
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     if (c->stream_c) (void)hipStreamSynchronize(c->stream_c);
     for (auto &S : c->sc) {
-        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.mdense, &S.label_a, &S.label_b};
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.label_a, &S.label_b};
         for (DevBuf *b : sb) release(*b);
         if (S.k1_done) (void)hipEventDestroy(S.k1_done);
         if (S.tail_done) (void)hipEventDestroy(S.tail_done);
@@ -454,7 +487,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -512,6 +545,7 @@ int lpf_release_to_stream(lpf_ctx *c, void *consumer)
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_release_to_stream inside graph capture");
+    { int rc_ = flush_pending(c); if (rc_) return rc_; }
     hipStream_t src[3] = {c->stream, c->stream_b, c->stream_c};
     for (int i = 0; i < 3; ++i) {
         if (i > 0 && !src[i]) continue;
@@ -575,18 +609,21 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (on < 0 || on > 3 || on == 2) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 3 = 1 + mask packing on a side stream)", on);
+    if (on < 0 || on > 3) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 2 the tail rides in the next run's launch, "
+                                                      "3 = 1 + mask packing on a side stream)", on);
     int rc = sync_all(c);
     if (rc) return rc;
-    if (on && !c->stream_b && (rc = make_side_streams(c))) return rc;
+    const bool streams = on == 1 || on == 3;
+    if (streams && !c->stream_b && (rc = make_side_streams(c))) return rc;
     for (auto &S : c->sc) {
-        if (on && !S.k1_done) {
+        if (streams && !S.k1_done) {
             LPF_HIP(c, hipEventCreateWithFlags(&S.k1_done, hipEventDisableTiming));
             LPF_HIP(c, hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
             LPF_HIP(c, hipEventCreateWithFlags(&S.mask_done, hipEventDisableTiming));
         }
     }
     c->pipelined = on != 0;
+    c->fused = on == 2;
     c->pack_side = on == 3;
     c->parity = 0;
     ++c->generation;
@@ -762,21 +799,34 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.cand_off = c->box_F ? c->cand_off[f] : 0;
         fr.cand_words = (fr.B + 63) / 64;
         fr.grp_off = ngrp_total;
+        fr.pad3 = 0; fr.pad4 = 0;
         const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
         ngrp_total += ngrp;
         if (ngrp > max_ngrp) max_ngrp = ngrp;
         if (fr.N > max_n) max_n = fr.N;
     }
     const int nseg_cap = nseg_total > 0 ? nseg_total : 1, ngrp_cap = ngrp_total > 0 ? ngrp_total : 1;
+    // tail blocks: four consecutive segments of one frame each (an empty frame still gets one, to write its summary);
+    // the list blocks, then -- when boxes are to be counted -- as many box-count blocks
+    const int M_ = c->mask_F ? c->mask_M : 0;
+    const bool count_boxes = M_ > 0 && c->box_F && c->box_off[F] > 0;
+    int nblk = 0;
+    for (int f = 0; f < F; ++f) {
+        const int nb = c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
+        nblk += nb;
+    }
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
     // a list wave sums one group's segments and the frame's groups, a lane each: frames of more than 64 groups
     // (16.7 M points) take their prefixes from the scan kernel instead
     const bool pre_scan = max_ngrp > 64 || c->geometry == 3;
 
     // pipelined device runs alternate between two scratch sets; everything else uses set 0 with both streams idle
-    const bool pipe = c->pipelined && !host_io && pts_on_device;
-    if (!pipe && c->stream_b && (c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c))) return rc;
-    lpf_ctx::Scratch &S = c->sc[pipe ? c->parity : 0];
+    const bool pipe_any = c->pipelined && !host_io && pts_on_device && !c->capturing;
+    const bool fused = pipe_any && c->fused;               // the tail rides in the next run's launch (three scratch sets)
+    const bool pipe = pipe_any && !c->fused;               // the tail runs on a second stream (two scratch sets)
+    if (!pipe_any && (c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c)))
+        return rc;                                         // set 0 is used with every stream idle and nothing owed
+    lpf_ctx::Scratch &S = c->sc[pipe_any ? c->parity : 0];
     hipStream_t tail_stream = pipe ? c->stream_b : c->stream;
     if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
     if ((rc = reserve(c, S.vbal, rows * 8))) return rc;
@@ -786,6 +836,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if ((rc = reserve(c, S.frm_tab, (size_t)F * LPF_FRM_SHARDS * LPF_TAB_GROUPS * sizeof(uint4), true))) return rc;
     if (pre_scan && (rc = reserve(c, S.seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
     if (F > 1 && (rc = reserve(c, c->segs, (size_t)nseg_cap * sizeof(LpfFrame)))) return rc;
+    if ((rc = reserve(c, c->blks, (size_t)nblk * sizeof(int2)))) return rc;
     if ((rc = reserve(c, S.cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
 
     LpfParams P;
@@ -804,6 +855,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
+    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -849,10 +901,6 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (M > 0) {                         // K1 -> K2 hand-off of the masked points (sparse writes into N slots)
         if ((rc = reserve(c, S.mlist, n * 16))) return rc;
         P.mlist = (float4 *)S.mlist.p;
-        if (Btot > 0) {                  // ... and their dense per-frame copy, which the box-count kernel reads
-            if ((rc = reserve(c, S.mdense, n * 16))) return rc;
-            P.mdense = (float4 *)S.mdense.p;
-        }
     }
 
     // The frame table only changes when the batch geometry does; upload it then (and wait, the
@@ -868,29 +916,86 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             if (nseg_total)
                 LPF_HIP(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), (size_t)nseg_total * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
         }
+        c->h_blks.clear();
+        for (int f = 0; f < F; ++f) {
+            const LpfFrame &fr = c->h_frames[f];
+            if (fr.nseg == 0) c->h_blks.push_back(make_int2(fr.seg_off, f << 3));
+            for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES)
+                c->h_blks.push_back(make_int2(fr.seg_off + sg, (f << 3) | std::min(LPF_LISTS_WAVES, fr.nseg - sg)));
+        }
+        LPF_HIP(c, hipMemcpyAsync(c->blks.p, c->h_blks.data(), c->h_blks.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
         LPF_HIP(c, hipStreamSynchronize(c->stream));
         c->h_frames_dev = c->h_frames;
         ++c->generation;                  // graphs captured for another geometry read these tables
     }
     if (pipe && S.tail_pending) LPF_HIP(c, hipStreamWaitEvent(c->stream, S.tail_done, 0));   // this set's previous tail
     if (pipe && S.mask_pending) { LPF_HIP(c, hipStreamWaitEvent(c->stream, S.mask_done, 0)); S.mask_pending = false; }
-    if (nseg_total > 0) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->profiling && c->ev_used < (1u << 16)) {
-            if (c->ev.size() < 2 * (c->ev_used + 1)) {
-                hipEvent_t a, b;
-                LPF_HIP(c, hipEventCreate(&a));
-                LPF_HIP(c, hipEventCreate(&b));
-                c->ev.push_back(a); c->ev.push_back(b);
-            }
-            e0 = c->ev[2 * c->ev_used]; e1 = c->ev[2 * c->ev_used + 1];
-            ++c->ev_used;
-            LPF_HIP(c, hipEventRecord(e0, c->stream));
+    // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
+    P.tile_pts = small ? 512 : 1024;
+    static const int lab_rows8 = getenv("LPF_LAB_ROWS8") ? atoi(getenv("LPF_LAB_ROWS8")) : 0;     // LAB: 2048-point tiles in the fused launch
+    if (fused && !small && lab_rows8) P.tile_pts = 2048;
+    const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
+    const int lb = (M > 0) ? S.label_bytes : 4;
+    const int ntail = nblk * (count_boxes ? 2 : 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((nk1 > 0 || fused) && c->profiling && c->ev_used < (1u << 16)) {
+        if (c->ev.size() < 2 * (c->ev_used + 1)) {
+            hipEvent_t a, b;
+            LPF_HIP(c, hipEventCreate(&a));
+            LPF_HIP(c, hipEventCreate(&b));
+            c->ev.push_back(a); c->ev.push_back(b);
         }
-        // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
-        P.tile_pts = small ? 512 : 1024;
-        const dim3 g1(nseg_total * (unsigned)(seg_pts / P.tile_pts));
-        const int lb = (M > 0) ? S.label_bytes : 4;
+        e0 = c->ev[2 * c->ev_used]; e1 = c->ev[2 * c->ev_used + 1];
+        ++c->ev_used;
+        LPF_HIP(c, hipEventRecord(e0, c->stream));
+    }
+    if (fused) {
+        // ---- one launch: this run's K1 tiles, the previous run's tail blocks dealt out among them, the summaries of the
+        //      run before that (lpf_step_t) ----------------------------------------------------------------------------
+        const lpf_ctx::Pending &Q = c->pend_tail, &R = c->pend_fin;
+        LpfStepLayout Y;
+        Y.nfin = R.valid ? R.P.F : 0;
+        Y.nfin8 = (Y.nfin + 7) & ~7;
+        Y.ntail = Q.valid ? Q.ntail : 0;
+        Y.nk1 = nk1;
+        const int nk1_pad = (nk1 + 7) & ~7;
+        Y.nper = (Y.ntail + 7) / 8;
+        Y.kper = 8;
+        if (Y.nper > 0) {                                  // spread the tail blocks over the first ~90 % of the tiles
+            static const int lab_spread = getenv("LPF_LAB_SPREAD") ? atoi(getenv("LPF_LAB_SPREAD")) : 90;   // LAB
+            const long long k = ((long long)nk1_pad * lab_spread / 100 / 8) / Y.nper;
+            Y.kper = (int)(k < 1 ? 1 : k) * 8;
+        }
+        const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
+        const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + (rest > 0 ? rest : 0);
+        if (grid > 0) {
+            const dim3 gs((unsigned)grid);
+            const LpfParams &QP = Q.valid ? Q.P : P, &RP = R.valid ? R.P : P;      // unused roles get a well-formed struct
+#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, P, QP, RP, Y)
+#define LPF_STEP_LT(RW, PR) do { if (lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
+            const bool qpre = Q.valid && Q.pre;
+            if (small) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
+            else if (P.tile_pts == 2048) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
+            else       { if (qpre) LPF_STEP_LT(4, true); else LPF_STEP_LT(4, false); }
+#undef LPF_STEP_LT
+#undef LPF_STEP_LAUNCH
+            LPF_HIP(c, hipGetLastError());
+        }
+        if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
+        if (pre_scan && nseg_total > 0) {                  // frames beyond 64 groups: their prefixes are scanned before the tail rides
+            hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+            LPF_HIP(c, hipGetLastError());
+        }
+        c->pend_fin = c->pend_tail;                        // its tail has just been launched: summaries in a later launch
+        c->pend_tail.valid = true;
+        c->pend_tail.P = P;
+        c->pend_tail.pre = pre_scan;
+        c->pend_tail.ntail = ntail;
+        c->parity = (c->parity + 1) % 3;
+        return LPF_OK;
+    }
+    if (nk1 > 0) {
+        const dim3 g1((unsigned)nk1);
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
         if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
         else       { if (lb == 1) LPF_K1_LAUNCH(4, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(4, uint16_t); else LPF_K1_LAUNCH(4, uint32_t); }
@@ -903,29 +1008,17 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         S.k1_recorded = true;
         LPF_HIP(c, hipStreamWaitEvent(tail_stream, S.k1_done, 0));
     }
-    // ---- the tail: lists (one wave per segment), box counts (the frame's masked points, densely), per-frame summary ----
-    if (nseg_total > 0) {
-        if (pre_scan) {
-            hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
-            LPF_HIP(c, hipGetLastError());
-        }
-        if (P.valid_idx || P.inst_idx || P.mdense) {
-            const dim3 g2((nseg_total + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES);
-            if (pre_scan) hipLaunchKernelGGL((lpf_lists_t<true>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-            else hipLaunchKernelGGL((lpf_lists_t<false>), g2, dim3(LPF_BLOCK), 0, tail_stream, P);
-            LPF_HIP(c, hipGetLastError());
-        }
-        if (P.mdense) {
-            // a frame's masked points are shared by up to `slices` blocks in chunks of 256; blocks past the end of the
-            // list leave at once (the host does not know how many points the masks caught)
-            long long slices = (max_n + 4095) / 4096, cap = 4096 / F;
-            if (slices > cap) slices = cap;
-            if (slices < 1) slices = 1;
-            hipLaunchKernelGGL(lpf_boxcount, dim3((unsigned)slices, (unsigned)F), dim3(LPF_BLOCK), 0, tail_stream, P);
-            LPF_HIP(c, hipGetLastError());
-        }
+    // ---- the tail: lists and box counts in one launch (a wave per segment each, side by side), then the per-frame summaries ----
+    if (pre_scan && nseg_total > 0) {
+        hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
+        LPF_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(lpf_k3_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
+    {
+        if (pre_scan) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+        else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+        LPF_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(lpf_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
     LPF_HIP(c, hipGetLastError());
 
     if (pipe) {

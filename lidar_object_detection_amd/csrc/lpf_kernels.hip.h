@@ -7,10 +7,10 @@
 //                      on an LDS-staged tile of packed bits                             (V3:82-97, V3:222)
 //   lpf_k1_project     float4 stream: 4x4 transform, cam2image, clip, label gather,
 //                      per-row wave ballots + per-segment counters                      (V3:565-569, 584, 225)
-//   lpf_lists          ballots -> stable valid / per-instance index lists (wave prefix) and the frame's
-//                      dense list of masked points                                       (V3:585, 228)
-//   lpf_boxcount       masked points x candidate boxes, slab test -> integer counters    (V3:187-202, 370)
-//   lpf_k3_finalize    first-strict-max box scan + per-frame summary                    (V3:353-379)
+//   lpf_tail           one launch for everything after K1:
+//     lists            ballots -> stable valid / per-instance index lists (wave prefix)  (V3:585, 228)
+//     box count        masked points x candidate boxes, slab test -> integer counters    (V3:187-202, 370)
+//     finalize         first-strict-max box scan + per-frame summary, by the frame's last block to arrive (V3:353-379)
 //
 // Arithmetic: everything the reference computes in float64 is float64 here, with the
 // summation order NumPy/OpenBLAS uses (see oracle/lpf_oracle.c); the file is compiled
@@ -40,6 +40,7 @@ struct LpfFrame {                // one per frame, device + host copy
     long long cand_off;          // first word of the frame's candidate-box grid
     int cand_words;              // 64-bit words per grid cell = ceil(B / 64)
     int grp_off;                 // first group (of LPF_GROUP_SEGS segments) of the frame
+    int pad3, pad4;
 };
 
 struct LpfParams {
@@ -57,6 +58,8 @@ struct LpfParams {
     LpfFrame frame0;             // the frame table by value when F == 1 (no dependent load)
     const LpfFrame *frames;      // [F]
     const LpfFrame *segs;        // [nseg_total] the owning frame's record per segment (pad = frame id)
+    const int2 *blks;            // [nblk] tail block table: {first segment, frame << 3 | segments (0..4)}
+    int nblk;
     const float4 *pts;
     const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
     const double *boxp;          // [Btot][16] exact box parameters
@@ -76,15 +79,14 @@ struct LpfParams {
     // scratch
     unsigned long long *vbal, *mbal;   // one 64-bit ballot per 64 points
     uint4 *seg_tab;              // [LPF_TAB_GROUPS][nseg_cap] per-segment counters, 4 per uint4;
-                                 // K1 tiles add into it, K3 leaves it zeroed
+                                 // K1 tiles add into it, the tail's finalizing block leaves it zeroed
     uint4 *grp_tab;              // [LPF_TAB_GROUPS][ngrp_cap] the same per group of LPF_GROUP_SEGS segments
     uint4 *frm_tab;              // [F][LPF_FRM_SHARDS][LPF_TAB_GROUPS] ... and per frame (sum the shards)
     uint4 *seg_pre;              // [LPF_TAB_GROUPS][nseg_cap] written by lpf_scan_segments (frames of more than 64 groups only)
-    unsigned *cnt;               // [M*Btot] inside counts (self-cleaned by K3)
+    unsigned *cnt;               // [M*Btot] inside counts (self-cleaned by the finalizing block)
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
                                  // bits} of its masked points in point order (nothing gathers from the cloud later)
-    float4 *mdense;              // [Ntot] per frame, at its first point: the same entries densely, in point order
-                                 // (written by lpf_lists, read by lpf_boxcount); null when no box is to be counted
+    int count_boxes;             // 1: the tail launch carries the box-count blocks
     int tile_pts;                // points per K1 tile of this launch (4 waves)
 };
 
@@ -159,6 +161,22 @@ __device__ __forceinline__ void lpf_project_point(const LpfParams &P, float fx, 
     lpf_div2(qx, qy, fabs(d), uf, vf);
 }
 
+// The same with the 21 constants read from memory (LDS: every lane reads the same word, a broadcast) instead of from
+// the kernel arguments: the tail kernel cannot afford the 42 SGPRs next to everything else it keeps.
+__device__ __forceinline__ void lpf_project_point_mem(const double *__restrict__ TK, float fx, float fy, float fz,
+                                                      double &uf, double &vf, double &d)
+{
+    const double x = (double)fx, y = (double)fy, z = (double)fz;
+    double cx = TK[0] * x; cx = fma(TK[1], y, cx); cx = fma(TK[2],  z, cx); cx = cx + TK[3];
+    double cy = TK[4] * x; cy = fma(TK[5], y, cy); cy = fma(TK[6],  z, cy); cy = cy + TK[7];
+    double cz = TK[8] * x; cz = fma(TK[9], y, cz); cz = fma(TK[10], z, cz); cz = cz + TK[11];
+    double qx = TK[12] * cx; qx = fma(TK[13], cy, qx); qx = fma(TK[14], cz, qx);
+    double qy = TK[15] * cx; qy = fma(TK[16], cy, qy); qy = fma(TK[17], cz, qy);
+    d = TK[18] * cx; d = fma(TK[19], cy, d); d = fma(TK[20], cz, d);
+    if (d == 0.0) d = -1e-6;
+    lpf_div2(qx, qy, fabs(d), uf, vf);
+}
+
 // ------------------------------------------------------------------------------------
 // K1: one block = one tile of 256*ROWS consecutive points of one frame (a segment of 4096 points is 4 or 8
 // tiles); a wave owns ROWS consecutive rows of 64 points.  All float4 loads of a lane are issued before the
@@ -182,7 +200,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
 {
     // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
     constexpr int TILE = LPF_BLOCK * ROWS;
-    static_assert(LPF_SEG_QUANTUM % TILE == 0 && LPF_SEG_SMALL % TILE == 0, "tiles must divide segments");
+    static_assert(LPF_SEG_QUANTUM % TILE == 0 && (LPF_SEG_SMALL % TILE == 0 || ROWS == 8), "tiles must divide segments (8-row tiles: large geometry only)");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const int tiles_per_seg = P.seg_pts / TILE;
     const int lb = lpf_xcd_remap(blk, P.nseg_total * tiles_per_seg);
@@ -503,16 +521,10 @@ __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, uns
 }
 
 template <bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
+__device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned short *lst)
 {
-    __shared__ unsigned short s_lidx[LPF_LISTS_WAVES][LPF_LIST_CAP];
-    const int lane = lpf_lane(), wave = lpf_wave();
-    const int sid = blockIdx.x * LPF_LISTS_WAVES + wave;
-    if (sid >= P.nseg_total) return;
+    const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // ---- round trip 1: everything that only depends on sid -------------------------------
-    LpfFrame fr = P.frame0;
-    if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];       // wave-uniform: scalar loads, one branch
     const int ngroups = (2 + P.M + 3) >> 2;
     const int rps = P.seg_pts >> 6;                        // ballot rows per segment: 16 or 64
     const int k = sid - fr.seg_off;                        // segment of its frame
@@ -557,7 +569,6 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
     const unsigned vbase = iv - cv, mbase = im - cm;
     const unsigned nv = lpf_rl(iv, 63), L = lpf_rl(im, 63);
     const long long run_v = (long long)lpf_rl(bef, 0);     // valid points of the frame before this segment
-    const unsigned run_m = lpf_rl(bef, 1);                 // masked points ...
 
     // ---- valid_idx: ascending by construction.  Sparse segment: every lane walks the set bits of its own row
     //      (as many steps as the fullest row has bits); dense one: row after row, a row's entries leave as one
@@ -589,8 +600,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
             }
         }
     }
-    const bool do_inst = P.inst_idx != nullptr, do_dense = P.mdense != nullptr;
-    if (L == 0 || !(do_inst || do_dense)) return;
+    if (L == 0 || P.inst_idx == nullptr) return;
 
     // lane m: where the next entry of mask m goes in the frame's concatenated lists
     unsigned posreg;
@@ -611,9 +621,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
     // row r, is entry e - mbase[first row of r's K1 wave] of that wave.
     const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
     const int rows_per_wave = P.tile_pts >> 8;             // K1 tile = 4 waves of tile_pts/4 points
-    const int rpw_shift = (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
-    float4 *__restrict__ dense = do_dense ? P.mdense + fr.pt_off + run_m : nullptr;
-    unsigned short *lst = s_lidx[wave];
+    const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
 
     for (int r0 = 0; r0 < nrows;) {                        // passes of at most LPF_LIST_CAP entries (one, except on very dense segments)
         const unsigned start = lpf_rl(mbase, r0);
@@ -629,11 +637,9 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
                 const unsigned li = lst[act ? e : 0];      // segment-relative point index
                 const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
                 const unsigned wb = (unsigned)__shfl((int)mbase, first_row);            // all lanes take part
-                float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act) pq = mseg[first_row * 64 + (int)(start + e - wb)];
-                const unsigned lab = __float_as_uint(pq.w);
-                if (dense && act) dense[start + e] = pq;   // 1 KiB contiguous per chunk
-                if (do_inst) {                             // split by instance; ballot order == ascending point index
+                unsigned lab = 0u;                         // only the label bits of the hand-off entry are needed here
+                if (act) lab = __float_as_uint(mseg[first_row * 64 + (int)(start + e - wb)].w);
+                {                                          // split by instance; ballot order == ascending point index
                     const long long idx = (long long)(seg_start + (int)li);
                     unsigned any = lpf_wave_or(lab);
                     while (any) {
@@ -658,50 +664,60 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_lists_t(const LpfParams P)
 
 // ------------------------------------------------------------------------------------
 // BOX COUNT: count_mb[m][b] = number of points of mask m inside box b (V3:344-376: np.sum(oriented_point_in_bbox(...))).
-// Grid (slices, frames): the blocks of a frame share its dense masked-point list in chunks of 256 (lane = masked point,
-// every lane busy whatever the scan order did to the segments).  The frame's candidate grid (built with the boxes)
-// lists, per 32x32-pixel cell, the boxes whose accepted region can project there; a point only meets those.
-// Candidates pass a conservative float AABB of the region first, the survivors are queued per wave and take the
-// reference's f64 test a whole wave at a time.  Hits are counted in LDS and flushed once per block.
+// One WAVE = one segment, like the lists -- and independent of them: the wave compacts its segment's masked points
+// itself (entry e -> ballot row by a binary search over the row prefixes -> K1 wave slot -> hand-off entry), so the
+// two run side by side in one launch.  The frame's candidate grid (built with the boxes) lists, per 32x32-pixel cell,
+// the boxes whose accepted region can project there; a point only meets those.  Candidates pass a conservative float
+// AABB of the region first, the survivors are queued per wave and take the reference's f64 test a whole wave at a
+// time.  Hits are counted in the block's LDS counters and flushed once per block.
 // ------------------------------------------------------------------------------------
-#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS
 #define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
+#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS (their float bounds: 64)
 
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_boxcount(const LpfParams P)
+__device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
+                                                  unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
+                                                  const double *s_tk)
 {
-    __shared__ float4 s_pt[4][64];                          // xyz + label of a wave's current chunk
-    __shared__ unsigned s_q[4][128];                        // (point, box) pairs that passed the float bounds
-    __shared__ float4 s_bq[2 * 64];                         // {lo, hi} float bounds of boxes 0..63
-    __shared__ double s_bp[LPF_BC_LDSB * 16];               // exact parameters of boxes 0..LPF_BC_LDSB-1
-    __shared__ unsigned s_cnt[LPF_BC_LDSCNT];
-    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const int f = blockIdx.y;
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
-    const int B = fr.B, M = P.M;
-    unsigned t = 0;
-    if (lane < LPF_FRM_SHARDS) t = P.frm_tab[((size_t)f * LPF_FRM_SHARDS + lane) * LPF_TAB_GROUPS].y;   // counter 1: masked points
-    const unsigned L = lpf_sum8(t);                        // block-uniform
-    if (L == 0 || B == 0 || M == 0 || (unsigned)blockIdx.x * LPF_BLOCK >= L) return;
+    const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const int rps = P.seg_pts >> 6;
+    const int k = sid - fr.seg_off;
+    unsigned long long mb = 0;
+    if (lane < rps) mb = P.mbal[(size_t)sid * rps + lane];
+    const int seg_start = k * P.seg_pts;
+    const int nrows = (min(seg_start + P.seg_pts, fr.N) - seg_start + 63) >> 6;
+    if (lane >= nrows) mb = 0;                             // rows K1 never wrote
+    const unsigned cm = __popcll(mb);
+    unsigned im = cm;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                     // inclusive scan over the row counts
+        const unsigned tm = __shfl_up(im, o);
+        if (lane >= o) im += tm;
+    }
+    const unsigned mbase = im - cm;
+    const unsigned L = lpf_rl(im, 63);
+    if (L == 0) return;
+    const int B = fr.B;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-    unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
-    const bool lds_cnt = M * B <= LPF_BC_LDSCNT;
-    if (tid < 2 * min(B, 64)) s_bq[tid] = boxq[tid];
-    for (int i = tid; i < min(B, LPF_BC_LDSB) * 16; i += LPF_BLOCK) s_bp[i] = boxp[i];
-    if (lds_cnt) for (int i = tid; i < M * B; i += LPF_BLOCK) s_cnt[i] = 0u;
-    __syncthreads();
-
-    const float4 *__restrict__ dense = P.mdense + fr.pt_off;
-    unsigned *qq = s_q[wave];
+    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+    const int rows_per_wave = P.tile_pts >> 8;
+    const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
     auto exact = [&](int count) {
         if (lane < count) {
             const unsigned ent = qq[lane];
             const int e = (int)(ent & 63u), b = (int)(ent >> 6);
-            const float4 x = s_pt[wave][e];
+            const float4 x = s_pt[e];
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
-            const double *bp = (b < LPF_BC_LDSB) ? s_bp + b * 16 : boxp + (size_t)b * 16;
-            const bool in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            bool in;
+            if (b < LPF_BC_LDSB) {
+                const double *bp = s_bp + b * 16;
+                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            } else {
+                const double *bp = boxp + (size_t)b * 16;
+                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            }
             if (in) {
                 unsigned l = __float_as_uint(x.w);
                 while (l) {
@@ -713,18 +729,29 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_boxcount(const LpfParams P)
             }
         }
     };
-    for (unsigned c0 = (unsigned)blockIdx.x * LPF_BLOCK; c0 < L; c0 += gridDim.x * LPF_BLOCK) {   // block-uniform
-        const unsigned e = c0 + tid;
+    for (unsigned e0 = 0; e0 < L; e0 += 64) {
+        const unsigned e = e0 + lane;
         const bool act = e < L;
-        const float4 p = dense[act ? e : c0];
+        // row of entry e: the first row whose inclusive prefix exceeds e (im is non-decreasing over the lanes)
+        int row = 0;
+#pragma unroll
+        for (int st = 32; st > 0; st >>= 1) {
+            const unsigned v = (unsigned)__shfl((int)im, row + st - 1);
+            if (v <= e) row += st;
+        }
+        row = min(row, 63);
+        const int first_row = (row >> rpw_shift) << rpw_shift;
+        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) p = mseg[first_row * 64 + (int)(e - wb)];
         __builtin_amdgcn_wave_barrier();
-        s_pt[wave][lane] = act ? p : make_float4(0.f, 0.f, 0.f, 0.f);      // .w carries the label bits
+        s_pt[lane] = p;                                     // .w carries the label bits (0 for idle lanes)
         __builtin_amdgcn_wave_barrier();
         int qn = 0;                                         // wave-uniform queue length
         int cell = 0;
         if (act) {                                          // same arithmetic as K1 => the same pixel; masked => valid => in range
             double uf, vf, d;
-            lpf_project_point(P, p.x, p.y, p.z, uf, vf, d);
+            lpf_project_point_mem(s_tk, p.x, p.y, p.z, uf, vf, d);
             cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
         }
         const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
@@ -760,33 +787,23 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_boxcount(const LpfParams P)
         exact(qn);
         __builtin_amdgcn_wave_barrier();
     }
-    if (lds_cnt) {
-        __syncthreads();
-        for (int i = tid; i < M * B; i += LPF_BLOCK) {
-            const unsigned v = s_cnt[i];
-            if (v) atomicAdd(&cnt[i], v);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------
-// K3: one block (4 waves) per frame.  Layout of lpf_frame_summary (include/lpf.h), in
-// int64 words: [0] n_valid  [1] n_labelled  [2..33] inst_count  [34..66] inst_off
-// [67..98] best_cnt, then int32: best_box[32], inst_overflow, reserved  => 928 bytes
+// FINALIZE (one block per frame): first strict maximum over the boxes + per-frame summary.
+// Layout of lpf_frame_summary (include/lpf.h), in int64 words: [0] n_valid  [1] n_labelled  [2..33] inst_count
+// [34..66] inst_off  [67..98] best_cnt, then int32: best_box[32], inst_overflow, reserved  => 928 bytes
 // ------------------------------------------------------------------------------------
 #define LPF_SUMMARY_BYTES 928
 
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
+__device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const LpfFrame &fr, const int f, unsigned *s_tot)
 {
-    const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const int B = fr.B, M = P.M;
     char *base = P.summary ? (char *)P.summary + (size_t)f * LPF_SUMMARY_BYTES : nullptr;
     long long *w = (long long *)base;
     int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
-    __shared__ unsigned s_tot[LPF_TAB_ROWS];
-    // the frame's totals: sum of the 8 shards K1's tiles added into; then the three counter levels are handed back
-    // zeroed for the next run (this kernel is the last reader)
+    // the frame's totals: sum of the 8 shards K1's tiles added into (K1 is a finished kernel: plain loads)
     const int ngroups = (2 + M + 3) >> 2;
     if (tid < LPF_TAB_ROWS) {
         unsigned a = 0;
@@ -797,21 +814,21 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
     }
     __syncthreads();
     const unsigned *__restrict__ tot = s_tot;
-    {
+    {   // ... and the three counter levels are handed back zeroed for the next run (this is their last reader)
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
         for (int i = tid; i < ngroups * fr.nseg; i += LPF_BLOCK) P.seg_tab[(size_t)(i / fr.nseg) * P.nseg_cap + fr.seg_off + (i % fr.nseg)] = z;
         for (int i = tid; i < ngroups * ngrp; i += LPF_BLOCK) P.grp_tab[(size_t)(i / ngrp) * P.ngrp_cap + fr.grp_off + (i % ngrp)] = z;
         for (int i = tid; i < LPF_FRM_SHARDS * LPF_TAB_GROUPS; i += LPF_BLOCK) P.frm_tab[(size_t)f * LPF_FRM_SHARDS * LPF_TAB_GROUPS + i] = z;
     }
-
-    // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
+    auto cnt_at = [&](int i) { return cnt[i]; };
+    // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     for (int m = wave; m < M; m += 4) {
         unsigned best = 0;
         int best_idx = 0x7fffffff;
         for (int b = lane; b < B; b += 64) {
-            const unsigned c = cnt[m * B + b];
+            const unsigned c = cnt_at(m * B + b);
             if (c > best) { best = c; best_idx = b; }      // ascending b per lane: keeps the first
         }
 #pragma unroll
@@ -849,9 +866,134 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k3_finalize(const LpfParams P)
     // hand the counters over and leave the scratch zeroed for the next call
     int32_t *out = P.count_out ? P.count_out + (size_t)M * fr.box_off : nullptr;
     for (int i = tid; i < M * B; i += LPF_BLOCK) {
-        if (out) out[i] = (int32_t)cnt[i];
+        if (out) out[i] = (int32_t)cnt_at(i);
         cnt[i] = 0;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// TAIL: lists and box counts in ONE launch.  Block table entry = up to four consecutive segments of one frame (a wave
+// each); blocks [0, nblk) build the lists of their segments, blocks [nblk, 2 nblk) -- present when boxes are to be
+// counted -- count their segments' masked points into the boxes.  Neither half needs anything from the other, and
+// nothing waits inside the kernel.  lpf_finalize then writes the per-frame summaries.
+// ------------------------------------------------------------------------------------
+struct LpfTailListsLds { unsigned short lidx[LPF_LISTS_WAVES][LPF_LIST_CAP]; };            // masked entries of a pass
+struct LpfTailCountLds {
+    float4 pt[LPF_LISTS_WAVES][64];           // xyz + label of a wave's current chunk
+    unsigned q[LPF_LISTS_WAVES][128];         // (point, box) pairs that passed the float bounds
+    unsigned cnt[LPF_BC_LDSCNT];              // the block's inside counts [M][B]
+    float4 bq[2 * 64];                        // {lo, hi} float bounds of the frame's boxes 0..63
+    double bp[LPF_BC_LDSB * 16];              // exact parameters of boxes 0..LPF_BC_LDSB-1
+    double tk[21];                            // T (12) and K (9)
+};
+
+#define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
+
+// one tail block: tb in [0, nblk) counts boxes (when there are any: the longer chain goes first), the next nblk build lists
+template <bool PRE>
+__device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb, char *s_raw)
+{
+    LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
+    LpfTailCountLds &LC = *reinterpret_cast<LpfTailCountLds *>(s_raw);
+    const int tid = threadIdx.x, wave = lpf_wave();
+    const bool count_role = P.count_boxes && tb < P.nblk;
+    const int2 ent = P.blks[(P.count_boxes && !count_role) ? tb - P.nblk : tb];       // {first segment, frame << 3 | segments}
+    const int f = ent.y >> 3, nw = ent.y & 7;
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    if (!count_role) {
+        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
+    } else {
+        const int MB = P.M * fr.B;
+        const bool lds_cnt = MB <= LPF_BC_LDSCNT;
+        if (lds_cnt) for (int i = tid; i < MB; i += LPF_BLOCK) LC.cnt[i] = 0u;
+        {   // box data of the frame and the camera constants -> LDS (one round trip for the block, issued before anything else)
+            const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
+            const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
+            if (tid < 2 * min(fr.B, 64)) LC.bq[tid] = boxq[tid];
+            for (int i = tid; i < min(fr.B, LPF_BC_LDSB) * 16; i += LPF_BLOCK) LC.bp[i] = boxp[i];
+            if (tid < 12) LC.tk[tid] = P.T[tid];
+            else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
+        }
+        __syncthreads();
+        if (wave < nw) lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
+        __syncthreads();
+        unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+        if (lds_cnt) {
+            for (int i = tid; i < MB; i += LPF_BLOCK) {
+                const unsigned v = LC.cnt[i];
+                if (v) atomicAdd(&cnt[i], v);
+            }
+        }
+    }
+}
+
+// 8 blocks per CU (all of a 16 M-point step's ~2000 blocks resident at once): <= 64 VGPRs, <= 80 SGPRs, <= 20 KB LDS
+template <bool PRE>
+__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
+{
+    __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
+    lpf_tail_block<PRE>(P, (int)blockIdx.x, s_raw);
+}
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
+{
+    __shared__ unsigned s_tot[LPF_TAB_ROWS];
+    const int f = blockIdx.x;
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    lpf_finalize_frame(P, fr, f, s_tot);
+}
+
+// ------------------------------------------------------------------------------------
+// STEP (software-pipelined mode): ONE launch carries the streaming kernel of run i, the tail of run i-1 and the
+// summaries of run i-2 -- three scratch sets, so nothing in a launch depends on anything else in it; the launch
+// boundaries order the runs' phases.  The tail's ~2000 short, latency-bound blocks are dealt out among the K1
+// tiles, eight (one per XCD) after every `kper` tiles, so they trickle through the chip beside the streaming
+// work instead of standing in front of it or behind it:
+//     blocks [0, nfin8)                               summaries of run i-2 (nfin8 = frames, padded to a multiple of 8)
+//     then nper periods of (kper K1 tiles, 8 tail blocks)
+//     then the remaining K1 tiles
+// A K1 block's XCD is blockIdx & 7 throughout (every offset is a multiple of 8), which lpf_k1_tile's tile
+// mapping relies on (speed only).
+// ------------------------------------------------------------------------------------
+struct LpfStepLayout {
+    int nfin, nfin8;             // summary blocks (frames of run i-2), padded
+    int ntail;                   // tail blocks of run i-1
+    int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
+    int nk1;                     // K1 tiles of run i
+};
+
+template <int ROWS, unsigned FL, typename LT, bool PRE>
+__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y)
+{
+    __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
+    __shared__ unsigned s_cnt[LPF_TAB_ROWS];
+    int b = (int)blockIdx.x;
+    if (b < Y.nfin8) {                                      // ---- summaries of run i-2
+        if (b < Y.nfin) {
+            const LpfFrame fr = (R.F > 1) ? R.frames[b] : R.frame0;
+            lpf_finalize_frame(R, fr, b, s_cnt);
+        }
+        return;
+    }
+    b -= Y.nfin8;
+    const int plen = Y.kper + 8, periodic = Y.nper * plen;
+    int vblk;                                               // K1: virtual block index, (rank on the XCD) << 3 | XCD
+    if (b < periodic) {
+        const int per = b / plen, pos = b - per * plen;
+        if (pos >= Y.kper) {                                // ---- tail of run i-1
+            const int tb = per * 8 + (pos - Y.kper);
+            if (tb < Y.ntail) lpf_tail_block<PRE>(Q, tb, s_raw);
+            return;
+        }
+        vblk = ((per * (Y.kper >> 3) + (pos >> 3)) << 3) | (pos & 7);
+    } else {
+        const int r = b - periodic;
+        vblk = ((Y.nper * (Y.kper >> 3) + (r >> 3)) << 3) | (r & 7);
+    }
+    // ---- K1 tile of run i: XCD x owns a contiguous run of count_x tiles (lpf_xcd_remap); the grid is padded per XCD
+    const int x = vblk & 7, q = Y.nk1 >> 3, rem = Y.nk1 & 7;
+    if ((vblk >> 3) >= q + (x < rem ? 1 : 0)) return;
+    lpf_k1_tile<ROWS, FL, LT>(P, vblk, s_cnt);
 }
 
 // ------------------------------------------------------------------------------------

@@ -286,7 +286,7 @@ def test_full_size_properties_2m(ctx, calib):
     _compare(r, o, 8, want_float=False)
 
 
-@pytest.mark.parametrize("pipelined", [False, True, "pack_side", "cus32", "cus64_exclusive_pack_side"])
+@pytest.mark.parametrize("pipelined", [False, True, "fused", "pack_side", "cus32", "cus64_exclusive_pack_side"])
 def test_device_mode_back_to_back_runs(calib, pipelined):
     """Device-pointer mode (torch tensors): several different batches enqueued back to back without
     host syncs, with and without the tail kernels on a second stream (optionally with the mask pack on a third, and
@@ -303,7 +303,7 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         if pipelined == "cus32":
             ctx.set_cu_partition(32)
-    ctx.set_pipelined(bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
+    ctx.set_pipelined("fused" if pipelined == "fused" else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     F, M, Bx = 3, 5, 7
     runs = []

@@ -6,7 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/sweep
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-"$R/tools/cumask_probe" > "$O/cumask_probe.txt" 2>&1; head -c 1500 "$O/cumask_probe.txt"; echo
 run() {  # tag, bench args...
   local tag=$1; shift
   timeout -k 10 200 python3 "$R/bench.py" --no-cpu --no-secondary --steps 200 --warmup 20 "$@" > "$O/$tag.json" 2> "$O/$tag.err" || { echo "$tag FAILED"; tail -3 "$O/$tag.err"; return 1; }
@@ -18,17 +17,8 @@ print("%-28s %7.2f us/step  K1 bracket %6.2f us  (step frac %.3f)" % (sys.argv[2
 PY
 }
 if [ "${1:-}" = "quick" ]; then
-run serial --mode serial && run pipeline --mode pipeline && run part32 --mode partition --side-cus 32 && run part64 --mode partition --side-cus 64 && \
-run part96 --mode partition --side-cus 96 && run pipe_cus64 --mode pipeline --side-cus 64 && run pipe_cus96 --mode pipeline --side-cus 96
+run serial --mode serial && run fused --mode fused && run pipeline --mode pipeline
 else
-run serial --mode serial && \
-run pipeline --mode pipeline && \
-run pipeline_pack --mode pipeline-pack && \
-run part16 --mode partition --side-cus 16 && \
-run part32 --mode partition --side-cus 32 && \
-run part64 --mode partition --side-cus 64 && \
-run part32x --mode partition --side-cus 32 --exclusive && \
-run part64x --mode partition --side-cus 64 --exclusive && \
-run pipe_cus32 --mode pipeline --side-cus 32 && \
-run pipe_cus64 --mode pipeline --side-cus 64
+run serial --mode serial && run fused --mode fused && run pipeline --mode pipeline && run pipeline_pack --mode pipeline-pack && \
+run part32 --mode partition --side-cus 32 && run part64 --mode partition --side-cus 64 && run part64x --mode partition --side-cus 64 --exclusive
 fi

@@ -8,7 +8,7 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- \
-    python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-events "$@" > "$out/bench.json" 2> "$out/bench.err"
+    python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-events --no-secondary "$@" > "$out/bench.json" 2> "$out/bench.err"
 echo "rocprofv3 exit $?" >> "$out/bench.err"
 f=$(ls -t "$out"/*/*kernel_stats.csv 2>/dev/null | head -1)
 cut -c1-200 "$out/bench.json" | tail -1
