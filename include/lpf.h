@@ -236,7 +236,9 @@ int lpf_profile_overhead(lpf_ctx *ctx, double *empty_bracket_ms);
  * (cvs:268-295): frames with rows, cars, matched cars, sums of total / inside / outside points, the inside
  * percentages as integer hundredths -- summed (op 0), or reduced by MIN (1) / MAX (2).  vec: host memory,
  * reduced in place over the caller's RCCL communicator (ncclComm_t, from ncclCommInitRank), one rank per GPU,
- * on the context's stream; returns when vec holds the result.  librccl is loaded at the first call. */
+ * on the context's stream; returns when vec holds the result -- it blocks, with no timeout, until every rank of the
+ * communicator has made the call.  ncclAllReduce is taken from the RCCL already loaded in the process (so that it is the
+ * library the communicator came from); only a process with none gets the system's librccl loaded at the first call. */
 int lpf_allreduce_metrics(lpf_ctx *ctx, int64_t *vec, int n, int op, void *rccl_comm);
 
 /* ---- scan reader ------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -96,7 +97,7 @@ struct lpf_ctx {
     hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
     hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
     // host-io staging
-    DevBuf pib_box, pib_pts, pib_out, boxprep, dimg;
+    DevBuf pib_box, pib_pts, pib_out, boxprep, dimg, coll;
     DevBuf st_uvv, st_labv;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
     std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
@@ -226,7 +227,8 @@ void box_params(const double *c, int oriented, double *o, float *q, double *vert
             double w = v0 * v0; w = std::fma(v1, v1, w); w = std::fma(v2, v2, w);
             o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = w;
             V[a][0] = v0; V[a][1] = v1; V[a][2] = v2; vv[a] = w;
-            if (!(w >= 1e-200 && w <= 1e200)) ok = false;      // also false for NaN
+            if (!(w >= 1e-100 && w <= 1e100)) ok = false;      // also false for NaN; the range in which the kernel's
+                                                               // division-free slab test is provably the quotient test (see lpf_oriented_inside)
         }
         o[15] = ok ? 1.0 : 0.0;            // 1: "0 <= d <= vv" decides the slab exactly (see kernel comment)
         // region = { p : 0 <= (p-c0).v_a <= vv_a }: vertices solve V x = sigma*vv, sigma in {0,1}^3
@@ -487,7 +489,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -855,7 +857,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
-    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
+    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0; P.count_split = 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -932,8 +934,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (pipe && S.mask_pending) { LPF_HIP(c, hipStreamWaitEvent(c->stream, S.mask_done, 0)); S.mask_pending = false; }
     // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
     P.tile_pts = small ? 512 : 1024;
-    static const int lab_rows8 = getenv("LPF_LAB_ROWS8") ? atoi(getenv("LPF_LAB_ROWS8")) : 0;     // LAB: 2048-point tiles in the fused launch
-    if (fused && !small && lab_rows8) P.tile_pts = 2048;
+    // the fused launch shares the chip with the previous run's tail blocks: 2048-point tiles keep twice the loads in flight
+    // per wave, so the streaming work holds its bandwidth on fewer resident blocks (measured: 104.9 vs 108.8 us per step)
+    if (fused && !small) P.tile_pts = 2048;
     const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
     const int lb = (M > 0) ? S.label_bytes : 4;
     const int ntail = nblk * (count_boxes ? 2 : 1);
@@ -962,8 +965,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         Y.nper = (Y.ntail + 7) / 8;
         Y.kper = 8;
         if (Y.nper > 0) {                                  // spread the tail blocks over the first ~90 % of the tiles
-            static const int lab_spread = getenv("LPF_LAB_SPREAD") ? atoi(getenv("LPF_LAB_SPREAD")) : 90;   // LAB
-            const long long k = ((long long)nk1_pad * lab_spread / 100 / 8) / Y.nper;
+            const long long k = ((long long)nk1_pad * 9 / 10 / 8) / Y.nper;     // (25 / 50 / 100 % measured within 2 us of this)
             Y.kper = (int)(k < 1 ? 1 : k) * 8;
         }
         const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
@@ -1238,24 +1240,35 @@ int lpf_allreduce_metrics(lpf_ctx *c, int64_t *vec, int n, int op, void *rccl_co
     if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_allreduce_metrics inside graph capture");
     typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
     typedef const char *(*errstr_fn)(int);
+    // The communicator belongs to whichever RCCL created it, and a process may hold more than one copy (torch wheels
+    // bundle their own): take ncclAllReduce from a library that is ALREADY loaded -- the global scope first, then the
+    // usual names without loading anything -- and only then load the system's librccl.  Resolved once (thread-safe).
     static allreduce_fn p_allreduce = nullptr;
     static errstr_fn p_errstr = nullptr;
-    if (!p_allreduce) {
-        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return fail(c, LPF_ERR_STATE, "allreduce_metrics: cannot load librccl.so (%s)", dlerror());
-        p_allreduce = (allreduce_fn)dlsym(h, "ncclAllReduce");
-        p_errstr = (errstr_fn)dlsym(h, "ncclGetErrorString");
-        if (!p_allreduce) return fail(c, LPF_ERR_STATE, "allreduce_metrics: librccl.so has no ncclAllReduce");
-    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            for (const char *name : {"librccl.so", "librccl.so.1"}) {
+                if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+            }
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllReduce");
+        }
+        p_allreduce = (allreduce_fn)sym;
+        p_errstr = (errstr_fn)(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    });
+    if (!p_allreduce) return fail(c, LPF_ERR_STATE, "allreduce_metrics: no ncclAllReduce in this process and librccl.so cannot be loaded (%s)", dlerror());
     int rc;
-    if ((rc = reserve(c, c->pib_out, (size_t)n * 8))) return rc;
-    LPF_HIP(c, hipMemcpyAsync(c->pib_out.p, vec, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = reserve(c, c->coll, (size_t)n * 8))) return rc;                 // a buffer of its own (lpf_points_in_boxes uses pib_out)
+    LPF_HIP(c, hipMemcpyAsync(c->coll.p, vec, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     static const int red[3] = {0 /* ncclSum */, 3 /* ncclMin */, 2 /* ncclMax */};
-    const int nrc = p_allreduce(c->pib_out.p, c->pib_out.p, (size_t)n, 4 /* ncclInt64 */, red[op], rccl_comm, c->stream);
+    const int nrc = p_allreduce(c->coll.p, c->coll.p, (size_t)n, 4 /* ncclInt64 */, red[op], rccl_comm, c->stream);
     if (nrc != 0) return fail(c, LPF_ERR_HIP, "ncclAllReduce failed: %s", p_errstr ? p_errstr(nrc) : "?");
-    LPF_HIP(c, hipMemcpyAsync(vec, c->pib_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, hipMemcpyAsync(vec, c->coll.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipStreamSynchronize(c->stream));          // blocks, with no timeout, until every rank has joined the collective
     return LPF_OK;
 }
 

@@ -87,6 +87,7 @@ struct LpfParams {
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
                                  // bits} of its masked points in point order (nothing gathers from the cloud later)
     int count_boxes;             // 1: the tail launch carries the box-count blocks
+    int count_split;             // 1: a box-count block is ONE segment, a quarter of its rows per wave (small launches)
     int tile_pts;                // points per K1 tile of this launch (4 waves)
 };
 
@@ -341,10 +342,13 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
 // K6 helpers: membership of one point in one box, from precomputed box parameters
 //   oriented: boxp = { c0[3], (v[3], vv) x 3, -, -, -, exact_ok }   (V3:187-202)
 //   aabb    : boxp = { lo[3], hi[3] }                               (V3:158-162)
-// The reference tests t = d / vv with 0 <= t <= 1.  For a positive normal vv and a d that
-// is zero or not tiny, round-to-nearest division gives  t >= 0 <=> d >= 0  and
-// t <= 1 <=> d <= vv  (the next double above vv is >= vv*(1+2^-53), which rounds above 1),
-// so the quotient is only formed for degenerate boxes / denormal-range d.
+// The reference tests t = d / vv with 0 <= t <= 1.  For 1e-100 <= vv <= 1e100 (exact_ok, set by the host) and a d that
+// is zero or at least 1e-200 in magnitude, round-to-nearest division gives
+//   t >= 0 <=> d >= 0 : |d| / vv >= 1e-300 is a normal number, so the quotient keeps d's sign (a smaller |d| / vv could
+//                       underflow to -0.0, which the reference counts as >= 0);  d = +-0 gives t = +-0, >= 0 both ways;
+//   t <= 1 <=> d <= vv: the next double above vv is vv + ulp(vv) with ulp(vv) / vv > 2^-53 strictly (equality would need
+//                       vv to be the power of two ABOVE its binade), so that quotient rounds to at least 1 + 2^-52;
+// NaN fails every comparison in both forms.  Everything else (degenerate boxes, tiny d) forms the quotient.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ bool lpf_oriented_inside(double px, double py, double pz, const double *__restrict__ b)
 {
@@ -355,7 +359,7 @@ __device__ __forceinline__ bool lpf_oriented_inside(double px, double py, double
         const double v0 = b[3 + 4 * a], v1 = b[4 + 4 * a], v2 = b[5 + 4 * a], vv = b[6 + 4 * a];
         double d = v1 * ry; d = fma(v0, rx, d); d = fma(v2, rz, d);   // dgemv_t tail order
         bool in;
-        if (exact_ok && !(fabs(d) < 1e-250 && d != 0.0)) {
+        if (exact_ok && !(fabs(d) < 1e-200 && d != 0.0)) {
             in = (d >= 0.0) && (d <= vv);
         } else {
             const double t = d / vv;
@@ -629,7 +633,14 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
         const int r1 = r0 + max(__popcll(fit), 1);         // rows [r0, r1): im is non-decreasing, so the fitting rows are a run
         const unsigned cnt = lpf_rl(im, r1 - 1) - start;
         if (cnt) {
-            if (lane >= r0 && lane < r1) lpf_bits_to_list(mb, mbase - start, lane, lst);
+            if (cnt > 6u * (unsigned)(r1 - r0)) {           // dense: row after row, lane = point
+                for (int r = r0; r < r1; ++r) {
+                    const unsigned long long rm = lpf_rl64(mb, r);
+                    if ((rm >> lane) & 1ull) lst[lpf_rl(mbase, r) - start + __popcll(rm & lt)] = (unsigned short)(r * 64 + lane);
+                }
+            } else if (lane >= r0 && lane < r1) {
+                lpf_bits_to_list(mb, mbase - start, lane, lst);
+            }
             __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: reads below see the writes
             for (unsigned e0 = 0; e0 < cnt; e0 += 64) {
                 const unsigned e = e0 + lane;
@@ -674,9 +685,11 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
 #define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
 #define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS (their float bounds: 64)
 
+// part < 0: the wave takes the whole segment; part = 0..3: its quarter of the segment's rows (small launches: a block per
+// segment, so that a segment lying on a car -- hundreds of masked points -- is four short chains instead of one long one)
 __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
                                                   unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
-                                                  const double *s_tk)
+                                                  const double *s_tk, const int part)
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -695,8 +708,13 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
         if (lane >= o) im += tm;
     }
     const unsigned mbase = im - cm;
-    const unsigned L = lpf_rl(im, 63);
-    if (L == 0) return;
+    unsigned e_lo = 0, L = lpf_rl(im, 63);                  // entries [e_lo, L) of the segment are this wave's
+    if (part >= 0) {
+        const int qr = rps >> 2;                           // rows per quarter
+        e_lo = lpf_rl(mbase, part * qr);
+        L = lpf_rl(im, part * qr + qr - 1);
+    }
+    if (L == e_lo) return;
     const int B = fr.B;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
@@ -729,7 +747,7 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
             }
         }
     };
-    for (unsigned e0 = 0; e0 < L; e0 += 64) {
+    for (unsigned e0 = e_lo; e0 < L; e0 += 64) {
         const unsigned e = e0 + lane;
         const bool act = e < L;
         // row of entry e: the first row whose inclusive prefix exceeds e (im is non-decreasing over the lanes)
@@ -889,15 +907,17 @@ struct LpfTailCountLds {
 
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
 
-// one tail block: tb in [0, nblk) counts boxes (when there are any: the longer chain goes first), the next nblk build lists
+// one tail block: the first nblk (4 nblk when split) count boxes (when there are any: the longer chain goes first), the next nblk build lists
 template <bool PRE>
 __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb, char *s_raw)
 {
     LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
     LpfTailCountLds &LC = *reinterpret_cast<LpfTailCountLds *>(s_raw);
     const int tid = threadIdx.x, wave = lpf_wave();
-    const bool count_role = P.count_boxes && tb < P.nblk;
-    const int2 ent = P.blks[(P.count_boxes && !count_role) ? tb - P.nblk : tb];       // {first segment, frame << 3 | segments}
+    const int ncount = P.count_boxes ? (P.count_split ? 4 * P.nblk : P.nblk) : 0;
+    const bool count_role = tb < ncount;
+    const int te = count_role ? (P.count_split ? tb >> 2 : tb) : tb - ncount;
+    const int2 ent = P.blks[te];                           // {first segment, frame << 3 | segments}
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
     if (!count_role) {
@@ -915,7 +935,11 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
             else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
         }
         __syncthreads();
-        if (wave < nw) lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
+        if (P.count_split) {                                // the block's four waves share one segment
+            if ((tb & 3) < nw) lpf_boxcount_wave(P, fr, ent.x + (tb & 3), LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, wave);
+        } else if (wave < nw) {
+            lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, -1);
+        }
         __syncthreads();
         unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
         if (lds_cnt) {

@@ -56,8 +56,11 @@ def _worker(rank, world, port, out_dir):
             return {f: _rows_for(f) for f in frames}
 
         rows, vec, lo, hi = D.run_sharded(_all_frames(), process_local, "cpu")
+        flat = [(f, r["car_id"], r["matched_bbox_id"], r["total_points"], r["points_inside_bbox"], r["inside_percentage"])
+                for f, rs in rows.items() for r in rs]
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), vec=vec, lo=lo, hi=hi, seen=np.array(seen),
-                 frames=np.array(list(rows.keys())), nrows=np.array([len(v) for v in rows.values()]))
+                 frames=np.array(list(rows.keys())), nrows=np.array([len(v) for v in rows.values()]),
+                 flat=np.array(flat, np.float64))
     finally:
         dist.destroy_process_group()
 
@@ -74,6 +77,9 @@ def test_sharded_aggregates_equal_single_process(tmp_path):
         assert np.array_equal(g["vec"], vec1) and int(g["lo"]) == int(lo1) and int(g["hi"]) == int(hi1)
         assert g["frames"].tolist() == sorted(frames)                    # gathered rows in frame order
         assert g["nrows"].tolist() == [len(single[f]) for f in sorted(frames)]
+        want = [(f, r["car_id"], r["matched_bbox_id"], r["total_points"], r["points_inside_bbox"], r["inside_percentage"])
+                for f in sorted(frames) for r in single[f]]
+        assert np.array_equal(g["flat"], np.array(want, np.float64))     # the padded int64 all-gather carries every row, bit for bit
     # the reduced aggregates print what pandas prints from the CSV
     csv = str(tmp_path / "m.csv")
     with contextlib.redirect_stdout(io.StringIO()) as out:
@@ -92,3 +98,19 @@ def test_shard_frames_covers_everything_once():
         parts = [D.shard_frames(frames, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == frames
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_row_codec_roundtrip_is_bit_exact():
+    rows = {100: _rows_for(100), 2717: [], 250: _rows_for(250)}
+    rows[100][0]["inside_percentage"] = 100.0 / 3.0                       # not representable in two decimals
+    rows[100][0]["color"] = (0.1, 0.2, 0.30000000000000004)
+    vec = D.encode_rows(rows)
+    back = D.decode_rows(np.concatenate([vec, np.zeros(37, np.int64)]))  # padding is ignored
+    assert list(back) == [100, 250, 2717] and back[2717] == []
+    for f in rows:
+        assert len(back[f]) == len(rows[f])
+        for a, b in zip(back[f], rows[f]):
+            for k in ("car_id", "matched_bbox_id", "total_points", "points_inside_bbox", "points_outside_bbox",
+                      "inside_percentage", "outside_percentage"):
+                assert a[k] == b[k]
+            assert tuple(a["color"]) == tuple(float(x) for x in b["color"])

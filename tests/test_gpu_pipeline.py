@@ -97,6 +97,25 @@ def test_point_in_box_operators(calib):
         pipeline.oriented_point_in_bbox(np.array([[0.1, 0.2, 0.3]]), g["corners_velo"][0])   # not float32-representable
 
 
+def test_slab_quotient_that_underflows_to_minus_zero(calib):
+    """V3:195-202 forms t = d / |v|^2 and accepts 0 <= t <= 1.  With a huge |v|^2 a tiny negative d gives t = -0.0, which
+    the reference counts as inside; a division-free test (d >= 0) would say outside.  The kernel only skips the division
+    where the two provably agree (1e-100 <= |v|^2 <= 1e100, |d| >= 1e-200 or d == 0) -- this box lies outside that range."""
+    def box(c0, v1, v2, v3):                                 # corners such that c1-c0, c3-c0, c4-c0 are the three slab vectors
+        c = np.zeros((8, 3))
+        c[0] = c0
+        c[1], c[3], c[4] = c0 + v1, c0 + v2, c0 + v3
+        return c
+    pts = np.array([[0.0, 0.5, 0.5], [0.0, 0.5, 1.5], [0.0, -0.5, 0.5]], np.float32)
+    for vx in (1e60, 1e45, 1e30):                            # |v|^2 = 1e120 (quotient path), 1e90 and 1e60 (division-free path)
+        c = box(np.array([1e-305, 0.0, 0.0]), np.array([vx, 0.0, 0.0]), np.array([0.0, 1.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+        want = orc.points_in_box(pts, c, True)
+        t = (pts[:, 0].astype(np.float64) - c[0, 0]) * vx / (vx * vx)
+        if vx == 1e60:
+            assert t[0] == 0.0 and np.signbit(t[0]) and want.tolist() == [True, False, False]     # the counter-example is one
+        assert np.array_equal(pipeline.oriented_point_in_bbox(pts, c), want), vx
+
+
 def test_all_sample_frames_in_one_batch(calib):
     """BASELINE configs[3] on one GPU: every sample frame (ragged N, M, B) in ONE batched call."""
     cam = _camera(calib)
