@@ -162,8 +162,26 @@ int lpf_get_label_image(lpf_ctx *ctx, uint32_t *out, int on_device);
 /* Box corners in the velodyne frame, f64 [Btot][8][3] in the dataset's corner order
  * (output of transform_bboxes_to_velodyne, V3:41-52); frame f owns boxes
  * [box_off[f], box_off[f+1]).  oriented = 1: oriented_point_in_bbox (V3:167-204, the
- * three skewed slabs c1-c0, c3-c0, c4-c0); 0: point_in_bbox (V3:143-164).  Host pointers. */
+ * three skewed slabs c1-c0, c3-c0, c4-c0); 0: point_in_bbox (V3:143-164).  box_off: host memory.
+ * The box tables (slab parameters in the reference's arithmetic, float bounds, per-cell candidate lists) are built
+ * by one kernel on the context's stream: no host work, and -- as long as the box COUNTS are those of the previous
+ * call -- no synchronisation, so a per-frame box change can sit inside a captured graph (lpf_set_boxes_ex with
+ * on_device = 1: the corners are read from the caller's device buffer when the graph runs).
+ * lpf_set_camera must come first; changing W or H afterwards drops the boxes. */
 int lpf_set_boxes(lpf_ctx *ctx, const double *corners_velo, const int32_t *box_off, int F, int oriented);
+int lpf_set_boxes_ex(lpf_ctx *ctx, const double *corners_velo, int on_device, const int32_t *box_off, int F, int oriented);
+/* The reference's per-frame box preparation and lpf_set_boxes in one device-side step (V3:556-562):
+ *   corners_cam0  f64 [Btot][8][3], the 'corners_cam0' of BBoxes_<frame>.json (host or device per on_device)
+ *   T_cam_to_velo inv(TrVeloToCam), row-major 4x4 (host)
+ *   filter_visible = 1: boxes that filter_visible_bboxes (V3:121-140) drops stay in the tables at their position but can
+ *                  never be hit: count_mb keeps one column per GIVEN box (zero for a dropped one) and best_box indexes the
+ *                  given list; the position in the reference's filtered list is the number of kept boxes before it.
+ * Optional outputs (NULL = not wanted; host or device like the input): visible[Btot] (1 = kept), corners_velo
+ * [Btot][8][3] (transform_bboxes_to_velodyne, V3:41-52), bbox2d [Btot][4] and front [Btot] as lpf_prepare_boxes.
+ * Device mode neither copies through the host nor synchronises (capturable under the rule above). */
+int lpf_set_boxes_cam0(lpf_ctx *ctx, const double *corners_cam0, int on_device, const int32_t *box_off, int F,
+                       const double T_cam_to_velo[16], int filter_visible, int oriented,
+                       uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front);
 
 /* ---- the hot path ----------------------------------------------------------------
  * Replaces, per frame: V3:565-569 (transform + cam2image), V3:584-592 (clip, np.where),

@@ -82,6 +82,8 @@ def load():
     lib.lpf_set_label_image.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_get_label_image.argtypes = [_P, _P, ctypes.c_int]
     lib.lpf_set_boxes.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_boxes_ex.argtypes = [_P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_boxes_cam0.argtypes = [_P, _P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
@@ -110,7 +112,7 @@ EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "l
             "lpf_set_pipelined",
             "lpf_set_cu_partition", "lpf_set_geometry", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
-            "lpf_get_label_image", "lpf_set_boxes", "lpf_run", "lpf_run_batch",
+            "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
             "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
@@ -409,6 +411,38 @@ class LpfContext:
         self._check(self._lib.lpf_set_boxes(self._h, cat.ctypes.data if cat.size else None, off.ctypes.data,
                                             len(arrs), int(bool(oriented))))
         self.box_off = off
+
+    def set_boxes_device(self, corners, box_off, oriented=True):
+        """Boxes from a torch float64 GPU tensor [Btot,8,3] (velodyne frame); box_off: host int32 [F+1].  Enqueues one kernel
+        on the context's stream; with unchanged box counts it neither copies nor synchronises (usable inside graph_begin/end)."""
+        off = np.ascontiguousarray(box_off, dtype=np.int32)
+        self._check(self._lib.lpf_set_boxes_ex(self._h, _dev_ptr(corners, "float64") if int(off[-1]) else None, 1, off.ctypes.data,
+                                               off.shape[0] - 1, int(bool(oriented))))
+        self.box_off = off
+
+    def set_boxes_cam0(self, corners_cam0_per_frame, T_cam_to_velo, filter_visible=True, oriented=True, want_outputs=True):
+        """The reference's per-frame box preparation (filter_visible_bboxes + transform_bboxes_to_velodyne, V3:556-562) and
+        set_boxes in one device-side step.  corners_cam0_per_frame: list of f64 [B_f,8,3] (or one array).  Box indices of later
+        results refer to the GIVEN boxes; dropped ones have zero counts.  Returns per frame (visible bool[B_f], corners_velo
+        [B_f,8,3], bbox2d [B_f,4], front int32[B_f]) unless want_outputs is False."""
+        if isinstance(corners_cam0_per_frame, np.ndarray):
+            corners_cam0_per_frame = [corners_cam0_per_frame]
+        arrs = [np.asarray(c, dtype=np.float64).reshape(-1, 8, 3) for c in corners_cam0_per_frame]
+        off = np.zeros(len(arrs) + 1, np.int32)
+        off[1:] = np.cumsum([a.shape[0] for a in arrs])
+        cat = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if arrs else np.zeros((0, 8, 3))
+        T = np.ascontiguousarray(T_cam_to_velo, dtype=np.float64).reshape(16)
+        B = int(off[-1])
+        vis, cv = np.zeros(B, np.uint8), np.zeros((B, 8, 3), np.float64)
+        bb, fr = np.zeros((B, 4), np.float64), np.zeros(B, np.int32)
+        w = want_outputs and B > 0
+        self._check(self._lib.lpf_set_boxes_cam0(self._h, cat.ctypes.data if B else None, 0, off.ctypes.data, len(arrs), T.ctypes.data,
+                                                 int(bool(filter_visible)), int(bool(oriented)), vis.ctypes.data if w else None,
+                                                 cv.ctypes.data if w else None, bb.ctypes.data if w else None, fr.ctypes.data if w else None))
+        self.box_off = off
+        if not want_outputs:
+            return None
+        return [(vis[a:b].astype(bool), cv[a:b], bb[a:b], fr[a:b]) for a, b in zip(off[:-1], off[1:])]
 
     def clear_boxes(self):
         self._check(self._lib.lpf_set_boxes(self._h, None, None, 0, 1))

@@ -61,11 +61,16 @@ struct lpf_ctx {
     std::vector<int32_t> box_off;     // F+1
     DevBuf boxp;                      // [Btot][16] double
     DevBuf boxq;                      // [Btot][8] float conservative AABB
-    DevBuf cand;                      // candidate-box grid (see build_candidates)
-    std::vector<double> box_verts;    // [Btot][8][3] vertices of each box's accepted region (velodyne frame)
-    std::vector<char> box_bounded;    // [Btot] 0: region unbounded / degenerate -> candidate everywhere
+    DevBuf cand;                      // candidate-box grid (lpf_box_setup_kernel)
+    DevBuf box_corners;               // [Btot][8][3] velodyne-frame corners the tables were built from (kept: a camera change rebuilds them)
+    DevBuf box_enabled;               // [Btot] bytes: 0 = dropped by filter_visible_bboxes (lpf_set_boxes_cam0), else null
+    DevBuf box_frames;                // [F] LpfBoxFrame
+    DevBuf box_aux;                   // lpf_set_boxes_cam0: projected 2D boxes + front counts
+    bool have_enabled = false;
+    std::vector<LpfBoxFrame> h_bframes, h_bframes_dev;
     std::vector<long long> cand_off;  // [F] first word of frame f's grid
-    bool cand_dirty = true;
+    size_t cand_words = 0;            // words of the whole grid
+    bool cand_dirty = true;           // the tables must be (re)built from box_corners before the next run
 
     // per-run scratch
     DevBuf frames, segs, blks;
@@ -284,64 +289,70 @@ void box_params(const double *c, int oriented, double *o, float *q, double *vert
     q[3] = 0.f; q[7] = 0.f;
 }
 
-// Candidate grid: bit b of cell (cy, cx) of frame f is set when box b's accepted region can
-// project into that 32x32-pixel cell of the image.  The region is convex and the camera is a
-// pinhole, so for a region entirely in front of the camera the projections of its 8 vertices
-// bound its image; regions that reach behind the camera (or are unbounded) are candidates
-// everywhere.  Purely a work-skipping structure: every candidate still takes the exact test.
 #define LPF_CELL_SHIFT 5
-int build_candidates(lpf_ctx *c, int F)
+// Box tables from the corners kept in box_corners: parameters, float bounds and the candidate grid, all on the device
+// (lpf_box_setup_kernel), on the context's stream, with no host work and no synchronisation -- capturable.
+int launch_box_setup(lpf_ctx *c)
 {
-    const int cs = LPF_CELL_SHIFT, cw = (c->W + (1 << cs) - 1) >> cs, ch = (c->H + (1 << cs) - 1) >> cs;
+    const int F = c->box_F, Btot = F ? c->box_off[F] : 0;
+    c->cand_dirty = false;
+    if (Btot == 0) return LPF_OK;
+    LpfBoxSetup A;
+    memcpy(A.T, c->T, sizeof A.T);
+    memcpy(A.K, c->K, sizeof A.K);
+    A.W = c->W; A.H = c->H; A.cell_shift = LPF_CELL_SHIFT;
+    A.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT; A.cell_h = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
+    A.oriented = c->oriented; A.F = F; A.Btot = Btot;
+    LPF_HIP(c, hipMemsetAsync(c->cand.p, 0, c->cand_words * 8, c->stream));
+    hipLaunchKernelGGL(lpf_box_setup_kernel, dim3((unsigned)((Btot + 3) / 4)), dim3(LPF_BLOCK), 0, c->stream, A,
+                       (const double *)c->box_corners.p, c->have_enabled ? (const uint8_t *)c->box_enabled.p : nullptr,
+                       (const LpfBoxFrame *)c->box_frames.p, (double *)c->boxp.p, (float *)c->boxq.p, (unsigned long long *)c->cand.p);
+    LPF_HIP(c, hipGetLastError());
+    return LPF_OK;
+}
+
+// Shapes of a box set: per-frame records, grid offsets, buffers.  The per-frame table only goes to the device when it
+// changed (then with a synchronisation, like the frame table of lpf_run_batch); otherwise nothing here blocks.
+int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const char *who)
+{
+    if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "%s: F=%d box_off=%p", who, F, (const void *)box_off);
+    if (F > 0 && box_off[0] != 0) return fail(c, LPF_ERR_ARG, "%s: box_off[0] must be 0", who);
+    for (int f = 0; f < F; ++f)
+        if (box_off[f + 1] < box_off[f]) return fail(c, LPF_ERR_ARG, "%s: box_off not ascending at %d", who, f);
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "%s: lpf_set_camera must be called first (the candidate grid is per image cell)", who);
+    int rc;
+    // pipelined modes: the tail of a run already queued / still owed reads the box tables -> drain first
+    if ((c->pipelined || c->pend_tail.valid || c->pend_fin.valid) && !c->capturing && (rc = sync_all(c))) return rc;
+    const int cw = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT, ch = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     const size_t ncell = (size_t)cw * ch;
+    c->h_bframes.resize((size_t)F);
     c->cand_off.assign((size_t)F, 0);
     size_t total = 0;
     for (int f = 0; f < F; ++f) {
-        const int B = c->box_off[f + 1] - c->box_off[f];
+        const int B = box_off[f + 1] - box_off[f];
+        c->h_bframes[f].box_off = box_off[f]; c->h_bframes[f].B = B; c->h_bframes[f].cand_off = (long long)total;
         c->cand_off[f] = (long long)total;
         total += ncell * (size_t)((B + 63) / 64);
     }
-    std::vector<unsigned long long> g(total ? total : 1, 0ull);
-    for (int f = 0; f < F; ++f) {
-        const int B = c->box_off[f + 1] - c->box_off[f], words = (B + 63) / 64;
-        unsigned long long *gf = g.data() + c->cand_off[f];
-        for (int b = 0; b < B; ++b) {
-            const int gb = c->box_off[f] + b;
-            int x0 = 0, x1 = cw - 1, y0 = 0, y1 = ch - 1;
-            bool everywhere = !c->box_bounded[gb];
-            if (!everywhere) {
-                double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-                for (int k = 0; k < 8 && !everywhere; ++k) {
-                    const double *p = &c->box_verts[(size_t)gb * 24 + 3 * k];
-                    double cam[3];
-                    for (int i = 0; i < 3; ++i) cam[i] = c->T[4 * i] * p[0] + c->T[4 * i + 1] * p[1] + c->T[4 * i + 2] * p[2] + c->T[4 * i + 3];
-                    const double qx = c->K[0] * cam[0] + c->K[1] * cam[1] + c->K[2] * cam[2];
-                    const double qy = c->K[3] * cam[0] + c->K[4] * cam[1] + c->K[5] * cam[2];
-                    const double d = c->K[6] * cam[0] + c->K[7] * cam[1] + c->K[8] * cam[2];
-                    if (!(d > 1e-3) || !std::isfinite(qx) || !std::isfinite(qy)) { everywhere = true; break; }
-                    const double u = qx / d, v = qy / d;
-                    if (u < umin) umin = u; if (u > umax) umax = u;
-                    if (v < vmin) vmin = v; if (v > vmax) vmax = v;
-                }
-                if (!everywhere) {
-                    umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;        // rounding of (u, v) + slack
-                    if (umax < 0 || vmax < 0 || umin > c->W || vmin > c->H) continue;   // never seen by a valid point
-                    x0 = umin <= 0 ? 0 : (int)umin >> cs; y0 = vmin <= 0 ? 0 : (int)vmin >> cs;
-                    x1 = umax >= c->W ? cw - 1 : (int)umax >> cs; y1 = vmax >= c->H ? ch - 1 : (int)vmax >> cs;
-                    if (x1 > cw - 1) x1 = cw - 1;
-                    if (y1 > ch - 1) y1 = ch - 1;
-                }
-            }
-            for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) gf[((size_t)y * cw + x) * words + (b >> 6)] |= 1ull << (b & 63);
+    const int Btot = F ? box_off[F] : 0;
+    if ((rc = reserve(c, c->boxp, (size_t)(Btot ? Btot : 1) * 16 * sizeof(double)))) return rc;
+    if ((rc = reserve(c, c->boxq, (size_t)(Btot ? Btot : 1) * 8 * sizeof(float)))) return rc;
+    if ((rc = reserve(c, c->cand, (total ? total : 1) * 8))) return rc;
+    if ((rc = reserve(c, c->box_corners, (size_t)(Btot ? Btot : 1) * 24 * sizeof(double)))) return rc;
+    if ((rc = reserve(c, c->box_frames, (size_t)(F ? F : 1) * sizeof(LpfBoxFrame)))) return rc;
+    if (c->h_bframes_dev.size() != c->h_bframes.size() ||
+        (F && memcmp(c->h_bframes_dev.data(), c->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame)) != 0)) {
+        if ((rc = sync_all(c))) return rc;
+        if (F) {
+            LPF_HIP(c, hipMemcpyAsync(c->box_frames.p, c->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame), hipMemcpyHostToDevice, c->stream));
+            LPF_HIP(c, hipStreamSynchronize(c->stream));
         }
+        c->h_bframes_dev = c->h_bframes;
+        ++c->generation;                                  // graphs captured for other box counts index these tables
     }
-    int rc;
-    if ((rc = sync_all(c))) return rc;
-    if ((rc = reserve(c, c->cand, g.size() * 8))) return rc;
-    LPF_HIP(c, hipMemcpyAsync(c->cand.p, g.data(), g.size() * 8, hipMemcpyHostToDevice, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));          // g is a local
-    c->cand_dirty = false;
+    c->cand_words = total;
+    c->box_off.assign(box_off, box_off + F + 1);
+    c->box_F = F; c->oriented = oriented ? 1 : 0;
     return LPF_OK;
 }
 
@@ -489,7 +500,7 @@ void lpf_destroy(lpf_ctx *c)
     }
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->box_corners, &c->box_enabled, &c->box_frames, &c->box_aux, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -656,7 +667,8 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!c) return LPF_ERR_ARG;
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
-    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; }   // label images are W x H
+    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->box_F = 0; c->box_off.clear(); }   // label images and the
+                                                                       // candidate grid are per W x H: set masks / boxes again
     memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
     memcpy(c->K, K, sizeof c->K);
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
@@ -725,36 +737,63 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
 
 int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int F, int oriented)
 {
+    return lpf_set_boxes_ex(c, corners, 0, box_off, F, oriented);
+}
+
+int lpf_set_boxes_ex(lpf_ctx *c, const double *corners, int on_device, const int32_t *box_off, int F, int oriented)
+{
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "set_boxes: F=%d box_off=%p", F, (const void *)box_off);
-    c->box_F = 0; c->box_off.clear();
-    { int rc_ = sync_all(c); if (rc_) return rc_; }       // the tail kernels of a pending run may still read the tables
-    ++c->generation;                                      // box tables are rewritten (and may move)
-    if (F == 0) return LPF_OK;
-    if (box_off[0] != 0) return fail(c, LPF_ERR_ARG, "set_boxes: box_off[0] must be 0");
-    for (int f = 0; f < F; ++f)
-        if (box_off[f + 1] < box_off[f]) return fail(c, LPF_ERR_ARG, "set_boxes: box_off not ascending at %d", f);
-    const int Btot = box_off[F];
-    if (Btot > 0 && !corners) return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL");
-    std::vector<double> bp((size_t)Btot * 16);
-    std::vector<float> bq((size_t)Btot * 8);
-    c->box_verts.assign((size_t)Btot * 24, 0.0);
-    c->box_bounded.assign((size_t)Btot, 0);
-    for (int b = 0; b < Btot; ++b)
-        box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data() + (size_t)b * 8,
-                   c->box_verts.data() + (size_t)b * 24, c->box_bounded.data() + b);
-    c->cand_dirty = true;
+    if (F == 0) { c->box_F = 0; c->box_off.clear(); return LPF_OK; }
     int rc;
-    if ((rc = reserve(c, c->boxp, bp.size() * sizeof(double)))) return rc;
-    if ((rc = reserve(c, c->boxq, bq.size() * sizeof(float)))) return rc;
-    if (Btot > 0) {
-        LPF_HIP(c, hipMemcpyAsync(c->boxp.p, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        LPF_HIP(c, hipMemcpyAsync(c->boxq.p, bq.data(), bq.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));      // bp, bq are locals
+    if ((rc = box_layout(c, box_off, F, oriented, "set_boxes"))) { c->box_F = 0; return rc; }
+    const int Btot = box_off[F];
+    if (Btot > 0 && !corners) { c->box_F = 0; return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL"); }
+    c->have_enabled = false;
+    if (Btot > 0)
+        LPF_HIP(c, hipMemcpyAsync(c->box_corners.p, corners, (size_t)Btot * 24 * sizeof(double),
+                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    return launch_box_setup(c);
+}
+
+int lpf_set_boxes_cam0(lpf_ctx *c, const double *corners_cam0, int on_device, const int32_t *box_off, int F, const double Tcv[16],
+                       int filter_visible, int oriented, uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (F == 0) { c->box_F = 0; c->box_off.clear(); return LPF_OK; }
+    int rc;
+    if (!Tcv) return fail(c, LPF_ERR_ARG, "set_boxes_cam0: T_cam_to_velo is NULL");
+    if ((rc = box_layout(c, box_off, F, oriented, "set_boxes_cam0"))) { c->box_F = 0; return rc; }
+    const int Btot = box_off[F];
+    if (Btot > 0 && !corners_cam0) { c->box_F = 0; return fail(c, LPF_ERR_ARG, "set_boxes_cam0: corners is NULL"); }
+    if (Btot == 0) { c->have_enabled = false; return LPF_OK; }
+    const size_t nb = (size_t)Btot;
+    // aux: {cam-0 corners (host callers), visible bytes come from box_enabled, 2D boxes, front counts}
+    const size_t o_in = 0, o_bb = o_in + nb * 192, o_fr = o_bb + nb * 32, total = o_fr + nb * 4;
+    if ((rc = reserve(c, c->box_aux, total))) return rc;
+    if ((rc = reserve(c, c->box_enabled, nb))) return rc;
+    char *aux = (char *)c->box_aux.p;
+    const double *d_in = corners_cam0;
+    if (!on_device) {
+        LPF_HIP(c, hipMemcpyAsync(aux + o_in, corners_cam0, nb * 192, hipMemcpyHostToDevice, c->stream));
+        d_in = (const double *)(aux + o_in);
     }
-    c->box_off.assign(box_off, box_off + F + 1);
-    c->box_F = F; c->oriented = oriented ? 1 : 0;
+    LpfBoxPrep A;
+    memcpy(A.Tcv, Tcv, sizeof A.Tcv);
+    memcpy(A.K, c->K, sizeof A.K);
+    A.W = c->W; A.H = c->H;
+    hipLaunchKernelGGL(lpf_box_prep_kernel, dim3((unsigned)((nb * 8 + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream, A, d_in,
+                       Btot, (uint8_t *)c->box_enabled.p, (double *)c->box_corners.p, (double *)(aux + o_bb), (int *)(aux + o_fr));
+    LPF_HIP(c, hipGetLastError());
+    c->have_enabled = filter_visible != 0;
+    if ((rc = launch_box_setup(c))) return rc;
+    const hipMemcpyKind back = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (visible) LPF_HIP(c, hipMemcpyAsync(visible, c->box_enabled.p, nb, back, c->stream));
+    if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, c->box_corners.p, nb * 192, back, c->stream));
+    if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, aux + o_bb, nb * 32, back, c->stream));
+    if (front) LPF_HIP(c, hipMemcpyAsync(front, aux + o_fr, nb * 4, back, c->stream));
+    if (!on_device && (visible || corners_velo || bbox2d || front)) LPF_HIP(c, hipStreamSynchronize(c->stream));
     return LPF_OK;
 }
 
@@ -783,7 +822,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     //      groups of 64 segments are the second level of the counters ------------------------------------------------
     const bool small = c->geometry == 1 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
     const int64_t seg_pts = small ? LPF_SEG_SMALL : LPF_SEG_QUANTUM;
-    if (c->box_F && c->cand_dirty && (rc = build_candidates(c, F))) return rc;
+    if (c->box_F && c->cand_dirty && (rc = launch_box_setup(c))) return rc;     // the camera changed since the boxes were set
     c->h_frames.resize(F);
     int nseg_total = 0, ngrp_total = 0, max_ngrp = 0;
     int64_t max_n = 0;
@@ -1148,17 +1187,18 @@ int lpf_prepare_boxes(lpf_ctx *c, const double *corners_cam0, int nbox, const do
     if (nbox < 0 || (nbox > 0 && (!corners_cam0 || !Tcv))) return fail(c, LPF_ERR_ARG, "prepare_boxes: nbox=%d", nbox);
     if (nbox == 0) return LPF_OK;
     const size_t nb = (size_t)nbox;
-    const size_t o_in = 0, o_T = o_in + nb * 192, o_K = o_T + 128, o_cv = o_K + 72 + 56 /*pad to 256*/, o_bb = o_cv + nb * 192,
-                 o_fr = o_bb + nb * 32, o_vis = o_fr + nb * 4, total = o_vis + nb;
+    const size_t o_in = 0, o_cv = o_in + nb * 192, o_bb = o_cv + nb * 192, o_fr = o_bb + nb * 32, o_vis = o_fr + nb * 4, total = o_vis + nb;
     int rc;
     if ((rc = reserve(c, c->boxprep, total))) return rc;
     char *base = (char *)c->boxprep.p;
     LPF_HIP(c, hipMemcpyAsync(base + o_in, corners_cam0, nb * 192, hipMemcpyHostToDevice, c->stream));
-    LPF_HIP(c, hipMemcpyAsync(base + o_T, Tcv, 128, hipMemcpyHostToDevice, c->stream));
-    LPF_HIP(c, hipMemcpyAsync(base + o_K, c->K, 72, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(lpf_box_prep_kernel, dim3((unsigned)((nb * 8 + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,
-                       (const double *)(base + o_in), nbox, (const double *)(base + o_T), (const double *)(base + o_K), c->W, c->H,
-                       (uint8_t *)(base + o_vis), (double *)(base + o_cv), (double *)(base + o_bb), (int *)(base + o_fr));
+    LpfBoxPrep A;
+    memcpy(A.Tcv, Tcv, sizeof A.Tcv);
+    memcpy(A.K, c->K, sizeof A.K);
+    A.W = c->W; A.H = c->H;
+    hipLaunchKernelGGL(lpf_box_prep_kernel, dim3((unsigned)((nb * 8 + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream, A,
+                       (const double *)(base + o_in), nbox, (uint8_t *)(base + o_vis), (double *)(base + o_cv), (double *)(base + o_bb),
+                       (int *)(base + o_fr));
     LPF_HIP(c, hipGetLastError());
     if (visible) LPF_HIP(c, hipMemcpyAsync(visible, base + o_vis, nb, hipMemcpyDeviceToHost, c->stream));
     if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, base + o_cv, nb * 192, hipMemcpyDeviceToHost, c->stream));

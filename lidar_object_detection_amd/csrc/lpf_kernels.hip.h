@@ -1077,12 +1077,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_depth_image_kernel(const LpfPar
 //                   ({umin, vmin, umax, vmax} as doubles; front[b] = number of such corners)
 // One thread per corner, 8 lanes per box; float64 with NumPy's dgemm order (k-ordered fma chains).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const double *__restrict__ corners_cam, int nbox,
-                                                                 const double *__restrict__ Tcv /*[16] cam->velo*/,
-                                                                 const double *__restrict__ K /*[9]*/, int W, int H,
+struct LpfBoxPrep { double Tcv[16]; double K[9]; int W, H; };     // cam -> velo transform, camera.K[:3,:3], image size
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const LpfBoxPrep A, const double *__restrict__ corners_cam, int nbox,
                                                                  uint8_t *__restrict__ visible, double *__restrict__ corners_velo,
                                                                  double *__restrict__ bbox2d, int *__restrict__ front)
 {
+    const double *Tcv = A.Tcv, *K = A.K;
+    const int W = A.W, H = A.H;
     const int t = blockIdx.x * LPF_BLOCK + threadIdx.x;
     const int b = t >> 3, k = t & 7;
     const bool live = b < nbox;
@@ -1115,10 +1117,174 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const double *_
             o[i] = a;
         }
         if (k == 0) {
-            visible[b] = (uint8_t)(nvis >= 2);
-            front[b] = nfront;
-            bbox2d[4 * b] = umin; bbox2d[4 * b + 1] = vmin; bbox2d[4 * b + 2] = umax; bbox2d[4 * b + 3] = vmax;
+            if (visible) visible[b] = (uint8_t)(nvis >= 2);
+            if (front) front[b] = nfront;
+            if (bbox2d) { bbox2d[4 * b] = umin; bbox2d[4 * b + 1] = vmin; bbox2d[4 * b + 2] = umax; bbox2d[4 * b + 3] = vmax; }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BOX SET-UP on the device (per frame, per box change; capturable): from the 8 velodyne-frame corners of every box
+//   boxp[b]  the oracle's slab parameters { c0, (v_a, |v_a|^2) x 3, exact_ok }  (oracle/lpf_oracle.c: orc_oriented_inside;
+//            V3:187-197) or { lo, hi } for the axis-aligned test (V3:158-162) -- the same operations in the same order as
+//            the reference's NumPy statements, so the counting kernels decide exactly as it does;
+//   boxq[b]  a conservative float AABB of the accepted region;
+//   cand     bit b of every 32x32-pixel cell the region can project into (the region is convex and the camera a
+//            pinhole, so the projections of its 8 vertices bound its image; a region reaching behind the camera, or an
+//            unbounded / degenerate one, is a candidate everywhere).
+// boxq and cand only skip hopeless (point, box) pairs: every candidate still takes the exact test.  One wave per box;
+// a box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no candidate cell.
+// ------------------------------------------------------------------------------------
+struct LpfBoxFrame {             // per frame, host-built from the box counts
+    int box_off, B;
+    long long cand_off;          // first word of the frame's grid
+};
+
+struct LpfBoxSetup {
+    double T[12], K[9];
+    int W, H, cell_shift, cell_w, cell_h, oriented, F, Btot;
+};
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_setup_kernel(const LpfBoxSetup A, const double *__restrict__ corners,
+                                                                  const uint8_t *__restrict__ enabled,
+                                                                  const LpfBoxFrame *__restrict__ bframes,
+                                                                  double *__restrict__ boxp, float *__restrict__ boxq,
+                                                                  unsigned long long *__restrict__ cand)
+{
+    const int lane = lpf_lane();
+    const int gb = blockIdx.x * 4 + lpf_wave();
+    if (gb >= A.Btot) return;                               // wave-uniform
+    int f = 0;                                              // the frame of the box: last f with box_off <= gb
+    {
+        int lo = 0, hi = A.F;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (bframes[mid].box_off <= gb) lo = mid; else hi = mid;
+        }
+        f = lo;
+    }
+    const LpfBoxFrame bf = bframes[f];
+    const int b = gb - bf.box_off, words = (bf.B + 63) >> 6;
+    const double *__restrict__ c = corners + (size_t)gb * 24;
+    double o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.0;
+    double lo3[3], hi3[3], vx[8], vy[8], vz[8];
+    bool bounded = true;
+    const bool on = !enabled || enabled[gb] != 0;
+    if (A.oriented) {
+        const int other[3] = {1, 3, 4};
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+        double V[3][3], vv[3];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double *q = c + 3 * other[a];
+            const double v0 = q[0] - c[0], v1 = q[1] - c[1], v2 = q[2] - c[2];
+            double w = v0 * v0; w = fma(v1, v1, w); w = fma(v2, v2, w);
+            o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = w;
+            V[a][0] = v0; V[a][1] = v1; V[a][2] = v2; vv[a] = w;
+            if (!(w >= 1e-100 && w <= 1e100)) ok = false;   // also false for NaN (see lpf_oriented_inside)
+        }
+        o[15] = ok ? 1.0 : 0.0;
+        // region = { p : 0 <= (p - c0) . v_a <= vv_a }: its vertices solve V x = sigma * vv, sigma in {0,1}^3
+        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+        const double scale = sqrt(vv[0]) * sqrt(vv[1]) * sqrt(vv[2]);
+        if (!ok || !(fabs(det) > 1e-6 * scale)) {
+            bounded = false;
+        } else {
+            double inv[3][3];
+            inv[0][0] = (V[1][1] * V[2][2] - V[1][2] * V[2][1]) / det; inv[0][1] = (V[0][2] * V[2][1] - V[0][1] * V[2][2]) / det;
+            inv[0][2] = (V[0][1] * V[1][2] - V[0][2] * V[1][1]) / det; inv[1][0] = (V[1][2] * V[2][0] - V[1][0] * V[2][2]) / det;
+            inv[1][1] = (V[0][0] * V[2][2] - V[0][2] * V[2][0]) / det; inv[1][2] = (V[0][2] * V[1][0] - V[0][0] * V[1][2]) / det;
+            inv[2][0] = (V[1][0] * V[2][1] - V[1][1] * V[2][0]) / det; inv[2][1] = (V[0][1] * V[2][0] - V[0][0] * V[2][1]) / det;
+            inv[2][2] = (V[0][0] * V[1][1] - V[0][1] * V[1][0]) / det;
+#pragma unroll
+            for (int sg = 0; sg < 8; ++sg) {
+                const double r0 = (sg & 1) ? vv[0] : 0.0, r1 = (sg & 2) ? vv[1] : 0.0, r2 = (sg & 4) ? vv[2] : 0.0;
+                vx[sg] = c[0] + inv[0][0] * r0 + inv[0][1] * r1 + inv[0][2] * r2;
+                vy[sg] = c[1] + inv[1][0] * r0 + inv[1][1] * r1 + inv[1][2] * r2;
+                vz[sg] = c[2] + inv[2][0] * r0 + inv[2][1] * r1 + inv[2][2] * r2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double a = c[k], bb = c[k];
+            for (int j = 1; j < 8; ++j) {
+                const double w = c[3 * j + k];
+                if (w < a) a = w;
+                if (w > bb) bb = w;
+            }
+            o[k] = a; o[3 + k] = bb;
+            if (!(a == a) || !(bb == bb)) bounded = false;
+        }
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) {
+            vx[sg] = (sg & 1) ? o[3] : o[0]; vy[sg] = (sg & 2) ? o[4] : o[1]; vz[sg] = (sg & 4) ? o[5] : o[2];
+        }
+    }
+    if (bounded) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo3[k] = 1e300; hi3[k] = -1e300; }
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) {
+            lo3[0] = fmin(lo3[0], vx[sg]); hi3[0] = fmax(hi3[0], vx[sg]);
+            lo3[1] = fmin(lo3[1], vy[sg]); hi3[1] = fmax(hi3[1], vy[sg]);
+            lo3[2] = fmin(lo3[2], vz[sg]); hi3[2] = fmax(hi3[2], vz[sg]);
+            if (!(vx[sg] == vx[sg]) || !(vy[sg] == vy[sg]) || !(vz[sg] == vz[sg])) bounded = false;   // fmin/fmax drop NaNs
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (!isfinite(lo3[k]) || !isfinite(hi3[k])) bounded = false;
+    }
+    if (lane < 16) boxp[(size_t)gb * 16 + lane] = on ? o[lane] : 0.0;
+    if (lane < 8) {
+        float q = 0.f;
+        const int k = lane & 3;
+        if (k < 3) {
+            if (!on) q = (lane < 4) ? INFINITY : -INFINITY;                       // empty: nothing is near
+            else if (!bounded) q = (lane < 4) ? -INFINITY : INFINITY;
+            else {
+                const double m = 1e-5 * (fabs(lo3[k]) + fabs(hi3[k]) + (hi3[k] - lo3[k])) + 1e-6;
+                q = (lane < 4) ? nextafterf((float)(lo3[k] - m), -INFINITY) : nextafterf((float)(hi3[k] + m), INFINITY);
+            }
+        }
+        boxq[(size_t)gb * 8 + lane] = q;
+    }
+    if (!on) return;
+    // ---- candidate cells --------------------------------------------------------------------------------
+    int x0 = 0, x1 = A.cell_w - 1, y0 = 0, y1 = A.cell_h - 1;
+    bool everywhere = !bounded;
+    if (!everywhere) {
+        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double cx = A.T[0] * vx[k] + A.T[1] * vy[k] + A.T[2] * vz[k] + A.T[3];
+            const double cy = A.T[4] * vx[k] + A.T[5] * vy[k] + A.T[6] * vz[k] + A.T[7];
+            const double cz = A.T[8] * vx[k] + A.T[9] * vy[k] + A.T[10] * vz[k] + A.T[11];
+            const double qx = A.K[0] * cx + A.K[1] * cy + A.K[2] * cz;
+            const double qy = A.K[3] * cx + A.K[4] * cy + A.K[5] * cz;
+            const double d = A.K[6] * cx + A.K[7] * cy + A.K[8] * cz;
+            if (!(d > 1e-3) || !isfinite(qx) || !isfinite(qy)) { everywhere = true; }
+            const double u = qx / d, v = qy / d;
+            umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+        }
+        if (!everywhere) {
+            umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;            // rounding of (u, v) + slack
+            if (umax < 0 || vmax < 0 || umin > A.W || vmin > A.H) return;   // never seen by a valid point
+            x0 = umin <= 0 ? 0 : (int)umin >> A.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> A.cell_shift;
+            x1 = umax >= A.W ? A.cell_w - 1 : (int)umax >> A.cell_shift; y1 = vmax >= A.H ? A.cell_h - 1 : (int)vmax >> A.cell_shift;
+            x1 = min(x1, A.cell_w - 1); y1 = min(y1, A.cell_h - 1);
+        }
+    }
+    unsigned long long *gf = cand + bf.cand_off;
+    const int nx = x1 - x0 + 1, ncell = nx * (y1 - y0 + 1);
+    const unsigned long long bit = 1ull << (b & 63);
+    for (int i = lane; i < ncell; i += 64) {
+        const int y = y0 + i / nx, x = x0 + i % nx;
+        atomicOr(&gf[((size_t)y * A.cell_w + x) * words + (b >> 6)], bit);
     }
 }
 

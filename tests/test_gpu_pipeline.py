@@ -10,6 +10,7 @@ import pytest
 
 from conftest import golden_frames, load_golden, unpack_masks
 from lidar_object_detection_amd import kitti360, pipeline
+from lidar_object_detection_amd._native import LpfContext
 from oracle import cpu_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -461,3 +462,89 @@ def test_allreduce_metrics_over_rccl_single_rank():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "frame%d" % r["frame"])
+def test_boxes_from_cam0_corners_on_the_device(rec, calib):
+    """V3:556-562 in one device-side step (lpf_set_boxes_cam0): the annotation's cam-0 corners go in, filter_visible_bboxes
+    and transform_bboxes_to_velodyne happen on the GPU, the box tables are built there.  Kept boxes: same corners and same
+    counts as the reference-generated golden vectors; dropped boxes: a zero column; best box: the same box."""
+    g = load_golden(rec["frame"])
+    if "corners_cam0_raw" not in g or "count_mb_rect5_d50" not in g:
+        pytest.skip("no boxes for this frame")
+    cam = _camera(calib)
+    masks = unpack_masks(g, "rect5", cam.height, cam.width)
+    M = len(masks)
+    pos = g["visible_pos"]
+    with LpfContext(0) as ctx:
+        ctx.set_camera(calib["TrVeloToRect"], cam.K, cam.width, cam.height, 0.0, 50.0)
+        ctx.set_masks(masks)
+        (vis, cv, bb, fr), = ctx.set_boxes_cam0(g["corners_cam0_raw"], np.linalg.inv(calib["TrVeloToCam"]))
+        assert np.array_equal(np.flatnonzero(vis), pos)
+        assert np.array_equal(cv[pos], g["corners_velo"])
+        r = ctx.run(g["points"])
+        cm = r["count_mb"]
+        assert cm.shape == (M, len(vis))
+        assert np.array_equal(cm[:, pos], g["count_mb_rect5_d50"]) and not cm[:, ~vis].any()
+        # the same boxes, already filtered, through the host-corner path: the best-box scan must name the same boxes
+        ctx.set_boxes(g["corners_velo"])
+        r2 = ctx.run(g["points"])
+        assert np.array_equal(r2["count_mb"], g["count_mb_rect5_d50"])
+        filtered = np.cumsum(vis) - 1                        # position in the reference's filtered list
+        for m in range(M):
+            if r2["best_box"][m] >= 0:
+                assert filtered[r["best_box"][m]] == r2["best_box"][m] and vis[r["best_box"][m]]
+            else:
+                assert r["best_box"][m] == -1
+            assert r["best_cnt"][m] == r2["best_cnt"][m]
+
+
+def test_hipgraph_with_boxes_that_change_every_replay(calib):
+    """The per-frame loop of the reference prepares a new box list for every frame (V3:556-562).  Captured once -- box
+    set-up from a device buffer, mask pack, the whole hot path -- and replayed on new points, masks AND boxes."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    n, M, Bx = 120_000, 5, 21
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream), LpfContext(0) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.set_camera(T, K, W, H, 0.0, 50.0)
+        sc0 = S.scene(n, n_masks=M, n_boxes=Bx, seed=900)
+        pts = torch.from_numpy(sc0["points"]).to(dev)
+        masks = torch.from_numpy(sc0["masks"]).to(dev)
+        corners = torch.from_numpy(np.ascontiguousarray(sc0["corners_velo"])).to(dev).contiguous()
+        off = np.array([0, n], np.int64)
+        boff = np.array([0, Bx], np.int32)
+        o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                 valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty(n, dtype=torch.int64, device=dev),
+                 count_mb=torch.zeros(M * Bx, dtype=torch.int32, device=dev),
+                 summary=torch.zeros(SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        step = ctx.make_device_step(pts, off, masks_u8=masks.unsqueeze(0), erode_iters=1, inst_cap=n, **o)
+
+        def frame():
+            ctx.set_boxes_device(corners, boff)
+            step()
+
+        frame()                                             # warm: allocations + table uploads happen here
+        ctx.sync()
+        ctx.graph_begin()
+        frame()
+        g = ctx.graph_end()
+        for k in range(3):
+            sc = S.scene(n, n_masks=M, n_boxes=Bx, seed=901 + k)
+            pts.copy_(torch.from_numpy(sc["points"]))
+            masks.copy_(torch.from_numpy(sc["masks"]))
+            corners.copy_(torch.from_numpy(np.ascontiguousarray(sc["corners_velo"])))
+            stream.synchronize()
+            ctx.graph_launch(g)
+            ctx.sync()
+            sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
+            ref = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=orc.pack_masks(sc["masks"], 1, H, W), M=M,
+                          corners=sc["corners_velo"], want_float=False)
+            assert int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(sm["inst_count"][:M], ref["inst_count"])
+            assert np.array_equal(o["count_mb"].cpu().numpy().reshape(M, Bx), ref["count_mb"]) and int(ref["count_mb"].sum()) > 0
+            assert np.array_equal(sm["best_box"][:M], ref["best_box"]) and np.array_equal(sm["best_cnt"][:M], ref["best_cnt"])
+        ctx.graph_destroy(g)
