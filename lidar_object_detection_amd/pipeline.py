@@ -42,8 +42,23 @@ def _f32_points(points, what="points"):
     return q
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
 def _mask_stack(masks, camera):
-    """[M,H,W] float32/uint8 array from the reference's mask list; identity resize only."""
+    """[M,H,W] float32/uint8 array from the reference's mask list; identity resize only.  A torch tensor that is
+    already on the GPU -- ``result.masks.data`` before the reference's ``.cpu().numpy()`` (V3:72) -- is passed through:
+    the kernels read it where it is."""
+    if _is_device_tensor(masks):
+        import torch
+        if masks.ndim != 3 or tuple(masks.shape[1:]) != (camera.height, camera.width):
+            raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64)" % (camera.height, camera.width))
+        if masks.dtype == torch.bool:
+            masks = masks.to(torch.uint8)
+        elif masks.dtype not in (torch.float32, torch.uint8):
+            masks = masks.to(torch.float32)
+        return masks.contiguous()
     m = np.asarray(masks)
     if m.size == 0:
         return np.zeros((0, camera.height, camera.width), np.uint8)
@@ -690,11 +705,18 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     M = max(s.shape[0] for s in stacks)
     if M > LPF_MAX_MASKS:
         raise NotImplementedError("more than %d detections in one frame" % LPF_MAX_MASKS)
-    is_f = any(s.dtype == np.float32 for s in stacks if s.shape[0])
-    dt = np.float32 if is_f else np.uint8
-    if all(s.shape[0] == M and s.dtype == dt for s in stacks):          # the usual case: no padding, no extra copy
-        batch = stacks[0][None] if len(stacks) == 1 else np.stack(stacks)
+    on_gpu = [_is_device_tensor(s) for s in stacks]
+    if any(on_gpu):                                                      # YOLO's masks still on the GPU: no host round trip
+        import torch
+        if not all(on_gpu) or any(s.shape[0] != M or s.dtype != stacks[0].dtype for s in stacks):
+            raise NotImplementedError("device masks: every frame of a batch needs the same detection count and dtype")
+        batch = stacks[0][None] if len(stacks) == 1 else torch.stack(stacks)
+        ctx.wait_for_stream(torch.cuda.current_stream(batch.device).cuda_stream)    # the masks were produced on torch's stream
+        stacks = [np.empty((M, 0, 0), np.uint8)] * len(stacks)          # only their detection count is used below
+    elif all(s.shape[0] == M and s.dtype == (np.float32 if any(t.dtype == np.float32 for t in stacks if t.shape[0]) else np.uint8) for s in stacks):
+        batch = stacks[0][None] if len(stacks) == 1 else np.stack(stacks)   # the usual case: no padding, no extra copy
     else:                                                               # ragged detection counts: pad with empty masks
+        dt = np.float32 if any(t.dtype == np.float32 for t in stacks if t.shape[0]) else np.uint8
         batch = np.zeros((len(frames), M, H, W), dt)
         for i, s in enumerate(stacks):
             if s.shape[0]:

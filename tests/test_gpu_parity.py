@@ -210,6 +210,44 @@ def test_mask_pack_and_erosion(ctx, calib, mode, iters):
     assert np.array_equal(ctx.get_label_image()[0], want)
 
 
+@pytest.mark.parametrize("binarize", ["astype", "v3", "gt0.5"])
+@pytest.mark.parametrize("iters", [0, 1, 2])
+def test_float_masks_from_a_device_tensor(ctx, calib, binarize, iters):
+    """SURVEY 8f-2's headline path: ``result.masks.data`` stays on the GPU (a float32 torch tensor, V3:72 minus the
+    .cpu().numpy()); threshold, erosion and packing happen there, for each of the three ways the reference reads a float mask."""
+    import torch
+    rng = np.random.default_rng(11)
+    W, H = int(calib["width"]), int(calib["height"])
+    F, M = 2, 6
+    base = (rng.random((F, M, H, W)) < 0.85).astype(np.float32)
+    base[0, 0] = 1.0
+    base[1, 1] = 0.0
+    base[0, 3] *= rng.choice(np.array([0.0, 0.5, 0.50000006, 0.999, 1.0, 1.5, 2.0, 256.0, np.nan, -1.0], np.float32), size=(H, W))
+    base[1, 4] *= rng.random((H, W)).astype(np.float32)                       # sigmoid-like values, not only 0 / 1
+    ctx.set_camera(calib["TrVeloToRect"], calib["K"], W, H, 0.0, 50.0)
+    dev = torch.device("cuda", 0)
+    t = torch.from_numpy(base).to(dev)
+    torch.cuda.synchronize(dev)                                           # (the fixture's context runs on its own stream)
+    ctx.set_masks(t, erode_iters=iters, binarize=binarize)
+    got = ctx.get_label_image()
+    for f in range(F):
+        member = orc.binarize_f32(base[f], {"astype": 0, "v3": 1, "gt0.5": 2}[binarize])
+        assert np.array_equal(got[f], orc.pack_masks(member, iters, H, W)), f
+    # ... and the hot path on those label images
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, _, _ = S.default_calibration(calib)
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    ctx.set_masks(t, erode_iters=iters, binarize=binarize)
+    pts = S.synthetic_cloud(60_000, seed=5)
+    ctx.clear_boxes()
+    rs = ctx.run_batch([pts, pts[:30_000]])
+    for f, (r, p) in enumerate(zip(rs, (pts, pts[:30_000]))):
+        member = orc.binarize_f32(base[f], {"astype": 0, "v3": 1, "gt0.5": 2}[binarize])
+        o = orc.run(p, T, K, W, H, 0.0, 50.0, label_img=orc.pack_masks(member, iters, H, W), M=M, corners=None, want_float=False)
+        assert np.array_equal(r["label_bits"], o["label_bits"]) and np.array_equal(r["inst_count"], o["inst_count"])
+        assert int(o["inst_count"].sum()) > 0
+
+
 def test_batch_equals_single_frames(ctx, calib):
     """run_batch over ragged frames == frame-by-frame runs == oracle."""
     from lidar_object_detection_amd import synthetic as S
@@ -348,16 +386,16 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
     ctx.close()
 
 
-def test_hipgraph_replay_matches_oracle(calib):
-    """BASELINE configs[4] mechanics: the per-frame launch set (mask pack + 1 erosion, project+label,
-    scan, lists, finalize) captured once into a hipGraph and replayed on new frame contents in the
-    same buffers; every replay must equal the oracle."""
+@pytest.mark.parametrize("n, M, Bx", [(150_000, 6, 9), (1_000_000, 8, 32)], ids=["150k", "configs4_1M_8masks_32boxes"])
+def test_hipgraph_replay_matches_oracle(calib, n, M, Bx):
+    """BASELINE configs[4]: the per-frame launch set (mask pack + 1 erosion, project+label, lists + box counts,
+    finalize) captured once into a hipGraph and replayed on new frame contents in the same buffers; every replay
+    must equal the oracle.  The second case is configs[4]'s own size: 1 M points, 8 eroded masks, 32 boxes."""
     import torch
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     _, T, K, W, H = S.default_calibration(calib)
     dev = torch.device("cuda", 0)
-    n, M, Bx = 150_000, 6, 9
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
         ctx = LpfContext(0)

@@ -548,3 +548,21 @@ def test_hipgraph_with_boxes_that_change_every_replay(calib):
             assert np.array_equal(o["count_mb"].cpu().numpy().reshape(M, Bx), ref["count_mb"]) and int(ref["count_mb"].sum()) > 0
             assert np.array_equal(sm["best_box"][:M], ref["best_box"]) and np.array_equal(sm["best_cnt"][:M], ref["best_cnt"])
         ctx.graph_destroy(g)
+
+
+def test_run_frames_with_masks_that_stay_on_the_gpu(calib):
+    """run_frames given YOLO's mask tensor as it is on the GPU (float32, no .cpu().numpy()) returns what it returns for
+    the same masks as host arrays -- the reference-generated golden statistics of frame 100."""
+    import torch
+    g = load_golden(100)
+    cam = _camera(calib)
+    masks = unpack_masks(g, "rect5", cam.height, cam.width)                # float32 [5,H,W]
+    boxes = [{"corners_velo": c.tolist()} for c in g["corners_velo"]]
+    dev = torch.device("cuda", 0)
+    a = pipeline.run_frames([pipeline.FrameInputs(100, g["points"], masks, boxes)], calib["TrVeloToRect"], cam, 50.0, 10, True)[0]
+    b = pipeline.run_frames([pipeline.FrameInputs(100, g["points"], torch.from_numpy(masks).to(dev), boxes)], calib["TrVeloToRect"],
+                            cam, 50.0, 10, True)[0]
+    assert [d["points_inside_bbox"] for d in b["car_statistics"]] == g["stats_points_inside_bbox_rect5_d50"].tolist()
+    assert np.array_equal(a["count_mb"], b["count_mb"]) and np.array_equal(a["valid_indices"], b["valid_indices"])
+    assert all(np.array_equal(x, y) for x, y in zip(a["car_point_sets"], b["car_point_sets"]))
+    assert np.array_equal(a["bg_assigned"], b["bg_assigned"])
