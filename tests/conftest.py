@@ -37,3 +37,20 @@ def unpack_masks(g, kind, H, W):
 @pytest.fixture(scope="session")
 def calib():
     return load_calib()
+
+
+def load_golden_full(frame):
+    """Full-size variant (tests/golden/make_golden.py, HASH_FRAMES): inputs in full, long outputs as SHA-256 digests."""
+    return dict(np.load(os.path.join(GOLDEN, "frame_%010d_full.npz" % frame)))
+
+
+def check_full(g, key, arr, dtype):
+    """arr == the reference's array ``key`` of a full-size golden: compared directly when it was stored, by length and
+    SHA-256 of its ``dtype`` bytes when only the digest was."""
+    import hashlib
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    if key in g:
+        assert np.array_equal(a, g[key]), key
+    else:
+        assert a.size == int(g[key + "_len"]), (key, a.size, int(g[key + "_len"]))
+        assert hashlib.sha256(a.tobytes()).digest() == g[key + "_sha256"].tobytes(), key

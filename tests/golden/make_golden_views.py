@@ -83,27 +83,22 @@ def main():
                first_match_color=np.array(m_color, np.float64).reshape(-1, 3),
                colors40=np.array(v5.generate_consistent_colors(40), np.int64))
 
-    # Same_color.py:113-131 on frame 100: statements of its main loop, re-typed here
+    # Same_color.py:114-132 on frame 100: the main loop's OWN source lines, sliced from the file and executed (G.run_ref).
+    # The loop collects points and colours, not indices: it is given points whose coordinates ARE their index and a
+    # palette whose colour i IS i, so both are read back from what it collected.
     z = np.load(os.path.join(HERE, "frame_0000000100.npz"))
     points = z["points"]
     masks = np.unpackbits(z["masks_edge_packed"], axis=2)[:, :, :camera.width].astype(np.float32)
     mask_colors = v5.generate_consistent_colors(len(masks))
-    pts = points.copy(); pts[:, 3] = 1
-    pointsCam = np.matmul(velo_to_rect, pts.T).T[:, :3]
-    u, v, depth = camera.cam2image(pointsCam.T)
-    u, v = u.astype(int), v.astype(int)
-    valid = (u >= 0) & (u < camera.width) & (v >= 0) & (v < camera.height) & (depth > 0) & (depth < 30)
-    col_idx, col_mask, bg_idx = [], [], []
-    for idx in np.where(valid)[0]:
-        x, y = u[idx], v[idx]
-        matched = False
-        for i, mask in enumerate(masks):
-            if y < mask.shape[0] and x < mask.shape[1] and mask[y, x] > 0.5:
-                col_idx.append(idx); col_mask.append(i)
-                matched = True
-                break
-        if not matched:
-            bg_idx.append(idx)
+    ns = G.run_ref("V3_point_cloud_with_erosion.py", 565, 569, {"np": np, "points": points, "TrVeloToRect": velo_to_rect, "camera": camera},
+                   "points_homo = points.copy()")
+    tagged = np.repeat(np.arange(len(points), dtype=np.float64)[:, None], 4, axis=1)
+    ns = G.run_ref("Same_color.py", 114, 132, {"np": np, "u": ns["u"], "v": ns["v"], "depth": ns["depth"], "camera": camera, "frame": 100,
+                                                "points": tagged, "masks": list(masks), "mask_colors": [(i, i, i) for i in range(len(masks))]},
+                   "valid = (u >= 0)")
+    col_idx = [int(p[0]) for p in ns["colored_points"]]
+    col_mask = [int(round(float(c[0]) * 255.0)) for c in ns["colored_colors"]]
+    bg_idx = [int(p[0]) for p in ns["full_points"]]
     res.update(samecolor_idx=np.array(col_idx, np.int64), samecolor_mask=np.array(col_mask, np.int8),
                samecolor_bg=np.array(bg_idx, np.int64),
                samecolor_colors=np.array([np.array(mask_colors[i]) / 255.0 for i in col_mask[:64]], np.float64))

@@ -7,7 +7,7 @@ the tolerance BASELINE.json's north_star states.
 import numpy as np
 import pytest
 
-from conftest import golden_frames, load_golden, unpack_masks
+from conftest import check_full, load_golden_full, golden_frames, load_golden, unpack_masks
 from oracle import cpu_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -544,3 +544,45 @@ def test_degenerate_boxes_and_nan_points(ctx, calib):
     lab = orc.pack_masks(masks, 0, H, W)
     o = orc.run(pts, T, K, W, H, 0.0, 50.0, label_img=lab, M=3, corners=corners)
     _compare(r, o, 3)
+
+
+FULL = [r["frame"] for r in golden_frames().get("full_frames", [])]
+
+
+@pytest.mark.parametrize("frame", FULL)
+@pytest.mark.parametrize("tag", ["rect5_d50", "rect5_d30", "edge_d50"])
+def test_full_size_golden_frames(ctx, calib, frame, tag):
+    """Sample frames 1461, 2098 and 2449 at FULL size against the reference-generated digests: real scan order (segments
+    on cars hold hundreds of masked points), up to 133 visible boxes (two candidate words per cell), and with the nine
+    'edge' masks M x B = 1197 > 1024 (the per-hit global-atomic path of the box count)."""
+    g = load_golden_full(frame)
+    kind, dmax = tag.split("_d")
+    W, H = int(calib["width"]), int(calib["height"])
+    masks = unpack_masks(g, kind, H, W)
+    M = masks.shape[0]
+    ctx.set_camera(calib["TrVeloToRect"], calib["K"], W, H, 0.0, float(dmax))
+    ctx.set_masks(masks)
+    ctx.set_boxes(g["corners_velo"])
+    r = ctx.run(g["points"], want_float=True, want_valid_uv=True)
+    check_full(g, "u", r["u"], np.int64)
+    check_full(g, "v", r["v"], np.int64)
+    check_full(g, "valid_idx_d" + dmax, r["valid_idx"], np.int64)
+    check_full(g, "inst_cat_" + tag, np.concatenate(r["inst_lists"]), np.int64)
+    check_full(g, "depth_s", r["depth"][::FS], np.float64)
+    check_full(g, "uf_s", r["uf"][::FS], np.float64)
+    check_full(g, "vf_s", r["vf"][::FS], np.float64)
+    check_full(g, "bg_assigned_" + tag, np.packbits(r["label_valid"] != 0), np.uint8)
+    assert np.array_equal(r["inst_count"], g["inst_count_" + tag])
+    assert np.array_equal(r["count_mb"], g["count_mb_" + tag])
+    rows = [m for m in range(M) if r["inst_count"][m] > 0]
+    assert np.array_equal(np.array([r["best_box"][m] if r["best_cnt"][m] >= 10 else -1 for m in rows], np.int64),
+                          g["stats_matched_bbox_id_" + tag])
+    assert np.array_equal(np.array([r["best_cnt"][m] if r["best_cnt"][m] >= 10 else 0 for m in rows], np.int64),
+                          g["stats_points_inside_bbox_" + tag])
+    ctx.set_boxes(g["corners_velo"], oriented=False)
+    assert np.array_equal(ctx.run(g["points"])["count_mb"], g["count_mb_aabb_" + tag])
+    # every annotated box of the frame (up to 314: five candidate words per cell), prepared on the device
+    (vis, cv, _, _), = ctx.set_boxes_cam0(g["corners_cam0_raw"], np.linalg.inv(calib["TrVeloToCam"]))
+    assert np.array_equal(np.flatnonzero(vis), g["visible_pos"]) and np.array_equal(cv[vis], g["corners_velo"])
+    cm = ctx.run(g["points"])["count_mb"]
+    assert np.array_equal(cm[:, vis], g["count_mb_" + tag]) and not cm[:, ~vis].any()
