@@ -58,7 +58,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(points_per_launch):
+def pmc_traffic(points_per_launch, kernel="lpf_k1_project_t"):
     """(HBM bytes per launch of the project+label kernel, provenance note).  The bytes come from the committed
     rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as tools/pmc_summary.py documents) and
     are only reported when those passes ran THIS source (sha of csrc/ recorded beside them) at this launch size;
@@ -75,9 +75,9 @@ def pmc_traffic(points_per_launch):
         return None, "profiles/%s was collected on kernel sources %s, these are %s: re-run tools/refresh_profiles.sh" % (
             PMC_FILE, meta.get("kernel_source_sha16"), kernel_source_sha())
     for k, v in d.items():
-        if "lpf_k1_project_t" in k:
+        if kernel in k:
             return v["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, kernel sources %s)" % (PMC_FILE, kernel_source_sha())
-    return None, "profiles/%s has no entry for the project+label kernel" % PMC_FILE
+    return None, "profiles/%s has no entry for %s" % (PMC_FILE, kernel)
 
 
 def usable_cpus(cgroup_root="/sys/fs/cgroup"):
@@ -161,7 +161,7 @@ MODES = {
     "fused": ("fused", False, 0, "software pipelining in one launch per step: the tail of step i-1 and the summaries of step i-2 "
                                  "ride among the streaming tiles of step i"),
 }
-DEFAULT_MODE = "serial"
+DEFAULT_MODE = "fused"
 
 
 def launch_ranks(args, argv):
@@ -430,100 +430,111 @@ def main():
         outs.append(make_outputs(torch, dev, ntot, F, ntot, N_MASKS, F * N_BOXES, SUMMARY_DTYPE.itemsize))
     frame_off = np.arange(F + 1, dtype=np.int64) * n
 
-    # Contexts run on streams of their own (a CU partition needs that).  Everything above was queued on torch's
-    # current stream, and the caching allocator may have carved the output tensors from memory that kernels still
-    # queued there read (the index tensors of the gathers): each context gets an explicit device-side edge behind
-    # that stream before its first kernel, instead of relying on a device-wide synchronisation ("The
-    # bench_s1 fault").
-    pipelined, pack_side, side_cus, _ = MODES[args.mode]
-    if args.side_cus >= 0:
-        side_cus = args.side_cus
-    nstream = max(1, min(args.streams, nbuf))
-    nbuf -= nbuf % nstream                                  # buffer b always belongs to context b % nstream
-    ctxs = []
-    for _ in range(nstream):
-        c = LpfContext(local_rank)
-        if side_cus:
-            c.set_cu_partition(side_cus, exclusive=args.exclusive)
-        c.set_pipelined(pipelined, pack_side=pack_side)
-        c.set_camera(T, K, W, H, 0.0, DMAX)
-        if args.lab != "noboxes":
-            c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box parameters resident in HBM
-        c.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
-        ctxs.append(c)
-    ctx = ctxs[0]
-
-    # one step = K8 mask pack (u8 masks in HBM -> label images) + K1 + scan + K2 + K3, pre-marshalled
-    if args.lab == "nolists":
-        for o in outs:
-            o["valid_idx"] = None
-            o["inst_idx"] = None
-    steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b],
-                                                   inst_cap=n, **outs[b])
-                for b in range(nbuf)]
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed(k):
-        barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(k):
-            steps_fn[i % nbuf]()
-        if world > 1:                                               # final aggregate metrics only
-            torch.cuda.synchronize(dev)                             # all streams: the last step may be on any of them
-            sm = np.frombuffer(outs[(k - 1) % nbuf]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
-            agg = torch.tensor([int(sm["n_valid"].sum()), int(sm["n_labelled"].sum()), int(sm["inst_count"].sum()), F],
-                               dtype=torch.int64, device=cdev)
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize(dev)
-        barrier()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=cdev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    def measure(mode, steps, warmup, events):
+        """`steps` timed steps under queueing mode `mode` (+ a second, event-bracketed pass), checked against the oracle."""
+        # Contexts run on streams of their own (a CU partition needs that).  Everything above was queued on torch's
+        # current stream, and the caching allocator may have carved the output tensors from memory that kernels still
+        # queued there read (the index tensors of the gathers): each context gets an explicit device-side edge behind
+        # that stream before its first kernel, instead of relying on a device-wide synchronisation (DESIGN.md, "The
+        # bench_s1 fault").
+        pipelined, pack_side, side_cus, _ = MODES[mode]
+        if args.side_cus >= 0:
+            side_cus = args.side_cus
+        nstream = max(1, min(args.streams, nbuf))
+        nb = nbuf - nbuf % nstream                          # buffer b always belongs to context b % nstream
+        ctxs = []
+        for _ in range(nstream):
+            c = LpfContext(local_rank)
+            if side_cus:
+                c.set_cu_partition(side_cus, exclusive=args.exclusive)
+            c.set_pipelined(pipelined, pack_side=pack_side)
+            c.set_camera(T, K, W, H, 0.0, DMAX)
+            if args.lab not in ("noboxes", "nowork"):
+                c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box tables resident in HBM
+            c.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
+            ctxs.append(c)
+        # one step = K8 mask pack (u8 masks in HBM -> label images) + project/label + lists + box counts + summaries, pre-marshalled
+        steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b],
+                                                       inst_cap=n, **outs[b])
+                    for b in range(nb)]
 
-    for i in range(args.warmup):
-        steps_fn[i % nbuf]()
-    torch.cuda.synchronize(dev)
-    elapsed = timed(args.steps)                                     # pass 1: the reported throughput
+        def drain():                                        # pipelined modes: launch what the last runs still owe, then wait
+            for c in ctxs:
+                c.sync()
+            torch.cuda.synchronize(dev)
 
-    k1_ms, k1_n, elapsed_ev, empty_ms = 0.0, 0, None, 0.0
-    if not args.no_events:                                          # pass 2: same steps, HIP events around K1
-        empty_ms = float(np.median([c.profile_overhead() for c in ctxs]))   # what an empty bracket measures, live
+        def timed(k):
+            barrier()
+            drain()
+            t0 = time.perf_counter()
+            for i in range(k):
+                steps_fn[i % nb]()
+            drain()                                         # inside the timed region: nothing of the k steps is left undone
+            if world > 1:                                   # final aggregate metrics only
+                sm = np.frombuffer(outs[(k - 1) % nb]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+                agg = torch.tensor([int(sm["n_valid"].sum()), int(sm["n_labelled"].sum()), int(sm["inst_count"].sum()), F],
+                                   dtype=torch.int64, device=cdev)
+                dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize(dev)
+            barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        for i in range(warmup):
+            steps_fn[i % nb]()
+        drain()
+        res = {"mode": mode, "steps": steps, "nbuf": nb, "nstream": nstream, "pipelined": bool(pipelined), "pack_side": bool(pack_side),
+               "side_cus": side_cus, "elapsed": timed(steps), "k1_ms": 0.0, "k1_n": 0, "elapsed_ev": None, "empty_ms": 0.0}
+        if events:                                          # pass 2: same steps, HIP events around the dominant kernel
+            res["empty_ms"] = float(np.median([c.profile_overhead() for c in ctxs]))   # what an empty bracket measures, live
+            for c in ctxs:
+                c.profile_enable(True)
+                c.profile_read(reset=True)
+            res["elapsed_ev"] = timed(steps)
+            for c in ctxs:
+                ms_c, n_c = c.profile_read(reset=True)
+                res["k1_ms"], res["k1_n"] = res["k1_ms"] + ms_c, res["k1_n"] + n_c
+                c.profile_enable(False)
+        # the numbers are only reported if the last step's results equal the CPU oracle's (frame 0, rank 0)
+        if rank == 0 and not args.lab:
+            from oracle import cpu_oracle as orc
+            b = (steps - 1) % nb
+            sm = np.frombuffer(outs[b]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+            pts_h = pts_dev[b][:n].cpu().numpy()
+            lab = orc.pack_masks(scenes[0]["masks"], 0, H, W)
+            o = orc.run(pts_h, T, K, W, H, 0.0, DMAX, label_img=lab, M=N_MASKS, corners=scenes[0]["corners_velo"],
+                        want_float=False)
+            ok = (int(sm[0]["n_valid"]) == o["n_valid"] and np.array_equal(sm[0]["inst_count"][:N_MASKS], o["inst_count"])
+                  and np.array_equal(outs[b]["count_mb"][:N_MASKS * N_BOXES].cpu().numpy().reshape(N_MASKS, N_BOXES), o["count_mb"])
+                  and np.array_equal(outs[b]["valid_idx"][:o["n_valid"]].cpu().numpy(), o["valid_idx"])
+                  and np.array_equal(outs[b]["uv"][:n].cpu().numpy(), np.stack([o["u"], o["v"]], axis=1))
+                  and np.array_equal(outs[b]["label_bits"][:n].cpu().numpy().view(np.uint32), o["label_bits"])
+                  and np.array_equal(sm[0]["best_box"][:N_MASKS], o["best_box"]))
+            if not ok:
+                raise SystemExit("bench (%s): GPU result differs from the CPU oracle -- refusing to report a number" % mode)
         for c in ctxs:
-            c.profile_enable(True)
-            c.profile_read(reset=True)
-        elapsed_ev = timed(args.steps)
-        for c in ctxs:
-            ms_c, n_c = c.profile_read(reset=True)
-            k1_ms, k1_n = k1_ms + ms_c, k1_n + n_c
-            c.profile_enable(False)
+            c.close()
+        return res
 
-    # the numbers are only reported if the last step's results equal the CPU oracle's (frame 0, rank 0)
-    if rank == 0 and not args.lab:
-        from oracle import cpu_oracle as orc
-        b = (args.steps - 1) % nbuf
-        sm = np.frombuffer(outs[b]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
-        pts_h = pts_dev[b][:n].cpu().numpy()
-        lab = orc.pack_masks(scenes[0]["masks"], 0, H, W)
-        o = orc.run(pts_h, T, K, W, H, 0.0, DMAX, label_img=lab, M=N_MASKS, corners=scenes[0]["corners_velo"],
-                    want_float=False)
-        ok = (int(sm[0]["n_valid"]) == o["n_valid"] and np.array_equal(sm[0]["inst_count"][:N_MASKS], o["inst_count"])
-              and np.array_equal(outs[b]["count_mb"][:N_MASKS * N_BOXES].cpu().numpy().reshape(N_MASKS, N_BOXES), o["count_mb"])
-              and np.array_equal(outs[b]["valid_idx"][:o["n_valid"]].cpu().numpy(), o["valid_idx"])
-              and np.array_equal(outs[b]["uv"][:n].cpu().numpy(), np.stack([o["u"], o["v"]], axis=1))
-              and np.array_equal(outs[b]["label_bits"][:n].cpu().numpy().view(np.uint32), o["label_bits"])
-              and np.array_equal(sm[0]["best_box"][:N_MASKS], o["best_box"]))
-        if not ok:
-            raise SystemExit("bench: GPU result differs from the CPU oracle -- refusing to report a number")
-
-    for c in ctxs:
-        c.close()
-    del steps_fn, pts_dev, masks_dev, outs, base_pts, masks0
+    if args.lab in ("nolists", "nowork"):
+        for o in outs:
+            o["valid_idx"] = None
+            o["inst_idx"] = None
+    main_run = measure(args.mode, args.steps, args.warmup, not args.no_events)
+    # the plain in-order queueing beside it (N = 1 only): what the pipelining buys, and the streaming kernel on its own
+    serial_run = None
+    if world == 1 and not args.no_secondary and args.mode != "serial" and not args.lab:
+        serial_run = measure("serial", min(args.steps, 100), min(args.warmup, 10), True)
+    elapsed, k1_ms, k1_n, elapsed_ev, empty_ms = (main_run[k] for k in ("elapsed", "k1_ms", "k1_n", "elapsed_ev", "empty_ms"))
+    nbuf, nstream, pipelined, pack_side, side_cus = (main_run[k] for k in ("nbuf", "nstream", "pipelined", "pack_side", "side_cus"))
+    del pts_dev, masks_dev, outs, base_pts, masks0
 
     if rank == 0:
         total_points = float(ntot) * args.steps * world
@@ -553,10 +564,11 @@ def main():
         if k1_n:
             dur_s = 1e-3 * k1_ms / k1_n                              # mean event bracket around the kernel
             achieved = ALGO_BYTES_PER_POINT * ntot / dur_s / 1e9
-            traffic, traffic_note = pmc_traffic(ntot)
+            traffic, traffic_note = pmc_traffic(ntot, "lpf_step_t" if args.mode == "fused" else "lpf_k1_project_t")
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                                "kernel": "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
+                                "kernel": "lpf_step_t (project+label tiles of this step + tail blocks of the previous one)" if args.mode == "fused"
+                                else "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "empty_bracket_us": 1e3 * empty_ms,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,
                                 "how": "second pass of the same %d steps with hipEvent pairs around the kernel on its stream "
@@ -571,6 +583,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scenes[0], T, K, W, H, args.cpu_seconds)
         if world == 1 and not args.no_secondary:
             line["secondary"] = secondary_lines(torch, dev, local_rank, T, K, W, H)
+            if serial_run is not None:
+                sd = 1e-3 * serial_run["k1_ms"] / max(serial_run["k1_n"], 1)
+                line["secondary"]["serial_queueing_same_workload"] = {
+                    "us_per_step": 1e6 * serial_run["elapsed"] / serial_run["steps"],
+                    "points_per_s": float(ntot) * serial_run["steps"] / serial_run["elapsed"],
+                    "k1_bracket_us": 1e6 * sd, "k1_algorithmic_GBps": ALGO_BYTES_PER_POINT * ntot / sd / 1e9,
+                    "k1_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / sd / 1e9 / HBM_PEAK_GBS,
+                    "note": "every kernel of a step on one stream, in order (pack, project+label, lists + box counts, summaries): the "
+                            "project+label kernel runs alone on the chip here"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
