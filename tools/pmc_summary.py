@@ -9,7 +9,8 @@ per-kernel HBM traffic per launch, with the gfx950 corrections of MI355X_MICROAR
 The gather part of a kernel's reads is doubled along with the stream, so the read figure is an
 upper bound.
 
-usage: pmc_summary.py <dir with pmc_*_FETCH_SIZE and pmc_*_WRITE_SIZE subdirs> <prefix> <out.json>
+usage: pmc_summary.py <dir with <prefix>_FETCH_SIZE and <prefix>_WRITE_SIZE subdirs> <prefix> [<prefix2> ...] <out.json>
+The output records, under "_meta", the sha of the kernel sources the passes ran (bench.py refuses a figure from other sources).
 """
 import collections
 import csv
@@ -26,12 +27,17 @@ def per_kernel(path):
 
 
 def main():
-    root, prefix, out = sys.argv[1:4]
+    root, prefixes, out = sys.argv[1], sys.argv[2:-1], sys.argv[-1]
     import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)       # a directory may hold earlier passes too
-    f = per_kernel(newest("%s/%s_FETCH_SIZE/*/*_counter_collection.csv" % (root, prefix)))
-    w = per_kernel(newest("%s/%s_WRITE_SIZE/*/*_counter_collection.csv" % (root, prefix)))
-    res = {}
+    f, w = {}, {}
+    for prefix in prefixes:
+        f.update(per_kernel(newest("%s/%s_FETCH_SIZE/*/*_counter_collection.csv" % (root, prefix))))
+        w.update(per_kernel(newest("%s/%s_WRITE_SIZE/*/*_counter_collection.csv" % (root, prefix))))
+    res = {"_meta": {"kernel_source_sha16": bench.kernel_source_sha(), "points_per_launch": 8 * bench.N_POINTS,
+                     "passes": prefixes, "corrections": "FETCH_SIZE KiB x 2 (gfx950, wide coalesced reads), WRITE_SIZE KiB exact"}}
     for k in sorted(set(f) | set(w)):
         if "lpf" not in k and "ref_" not in k:
             continue
@@ -41,6 +47,8 @@ def main():
                   "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
+        if k == "_meta":
+            continue
         print("%-60s %10.1f MB read  %10.1f MB written" % (k[-60:], v["read_bytes_corrected"] / 1e6, v["write_bytes"] / 1e6))
 
 
