@@ -6,6 +6,7 @@ tensors are passed by ``data_ptr()`` in device mode.
 """
 import ctypes
 import os
+import sys
 import weakref
 
 import numpy as np
@@ -57,6 +58,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # A process that also uses PyTorch must end up with ONE HIP runtime.  The torch wheel bundles its own libamdhip64.so;
+    # if liblpf.so pulls in the system copy first, torch's later initialisation fails ("No HIP GPUs are available").
+    # Importing torch first makes its copy the one both use (same SONAME).  LPF_NO_TORCH_PRELOAD=1 skips this.
+    if "torch" not in sys.modules and not os.environ.get("LPF_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise LpfError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

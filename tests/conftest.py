@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                     # torch's bundled HIP runtime has to be the first one loaded in a process that uses both
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
