@@ -164,14 +164,17 @@ MODES = {
 DEFAULT_MODE = "fused"
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, dry=False):
     """`python bench.py --gpus N` with no launcher around it: this parent makes no GPU call; it starts the N ranks
     as a child `python -m torch.distributed.run ... bench.py <same arguments>` and leaves with the child's exit code."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    if dry:
+        print(json.dumps({"would_launch": args.gpus, "cmd": cmd}))
+        return 0
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -379,10 +382,7 @@ def main():
         args.mode = "pipeline"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if args.dry_launch:
-            print(json.dumps({"would_launch": args.gpus}))
-            return 0
-        return launch_ranks(args, sys.argv[1:])
+        return launch_ranks(args, sys.argv[1:], dry=args.dry_launch)
 
     import torch
     import torch.distributed as dist
@@ -519,6 +519,9 @@ def main():
                   and np.array_equal(sm[0]["best_box"][:N_MASKS], o["best_box"]))
             if not ok:
                 raise SystemExit("bench (%s): GPU result differs from the CPU oracle -- refusing to report a number" % mode)
+            res["n_valid_batch"] = int(sm["n_valid"].sum())
+            res["n_masked_batch"] = int(sm["n_labelled"].sum())
+            res["n_list_entries_batch"] = int(sm["inst_count"].sum())
         for c in ctxs:
             c.close()
         return res
@@ -565,12 +568,22 @@ def main():
             dur_s = 1e-3 * k1_ms / k1_n                              # mean event bracket around the kernel
             achieved = ALGO_BYTES_PER_POINT * ntot / dur_s / 1e9
             traffic, traffic_note = pmc_traffic(ntot, "lpf_step_t" if args.mode == "fused" else "lpf_k1_project_t")
+            # SURVEY 8(d) asks for both figures: the strict 28 B per input point (-> achieved, frac) and the itemised total
+            # of what this launch produces: + 4 B label-image gather per valid point and, when the launch carries the list
+            # blocks too (the fused step), + 8 B valid_idx per valid point + 8 B per instance-list entry
+            itemised = None
+            if "n_valid_batch" in main_run:
+                itemised = ALGO_BYTES_PER_POINT * ntot + 4 * main_run["n_valid_batch"]
+                if args.mode == "fused":
+                    itemised += 8 * main_run["n_valid_batch"] + 8 * main_run["n_list_entries_batch"]
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                 "kernel": "lpf_step_t (project+label tiles of this step + tail blocks of the previous one)" if args.mode == "fused"
                                 else "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "empty_bracket_us": 1e3 * empty_ms,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,
+                                "algorithmic_bytes_itemised": itemised,
+                                "achieved_itemised": itemised / dur_s / 1e9 if itemised else None,
                                 "how": "second pass of the same %d steps with hipEvent pairs around the kernel on its stream "
                                        "(ms_per_step of that pass: %.4f). avg_us is the mean bracket as measured: two event "
                                        "records with nothing between them measure empty_bracket_us on the same stream, so the "
