@@ -201,7 +201,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
 {
     // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
     constexpr int TILE = LPF_BLOCK * ROWS;
-    static_assert(LPF_SEG_QUANTUM % TILE == 0 && (LPF_SEG_SMALL % TILE == 0 || ROWS == 8), "tiles must divide segments (8-row tiles: large geometry only)");
+    static_assert(LPF_SEG_QUANTUM % TILE == 0 && (LPF_SEG_SMALL % TILE == 0 || ROWS >= 8), "tiles must divide segments (8-row and larger tiles: large geometry only)");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
     const int tiles_per_seg = P.seg_pts / TILE;
     const int lb = lpf_xcd_remap(blk, P.nseg_total * tiles_per_seg);

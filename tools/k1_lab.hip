@@ -1,5 +1,5 @@
-// tools/k1_lab.hip -- development harness (not part of the product): times ablation
-// variants of the project+label kernel back to back in one process on one GPU.
+// tools/k1_lab.hip -- development harness (not part of the product): times reference copy kernels and
+// variants of the project+label kernel (rows per wave, resident blocks per CU) back to back in one process on one GPU.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/k1_lab tools/k1_lab.hip
 #include "../lidar_object_detection_amd/csrc/lpf_kernels.hip.h"
 #include <cstdio>
@@ -116,6 +116,13 @@ int main(int argc, char **argv)
     memcpy(P.T, T, sizeof T); memcpy(P.K, K, sizeof K);
     P.dmin = 0; P.dmax = 30; P.W = W; P.H = H; P.F = 1; P.M = 8; P.frames = d_fr; P.label_img = d_limg;
     P.vbal = vbal; P.mbal = mbal; P.seg_tab = tab;
+    {   // the other two counter levels K1's tiles add into
+        uint4 *grp, *frm;
+        CK(hipMalloc(&grp, LPF_TAB_GROUPS * (maxseg / LPF_GROUP_SEGS + 1) * 16)); CK(hipMemset(grp, 0, LPF_TAB_GROUPS * (maxseg / LPF_GROUP_SEGS + 1) * 16));
+        CK(hipMalloc(&frm, LPF_FRM_SHARDS * LPF_TAB_GROUPS * 16)); CK(hipMemset(frm, 0, LPF_FRM_SHARDS * LPF_TAB_GROUPS * 16));
+        P.grp_tab = grp; P.frm_tab = frm; P.ngrp_cap = (int)(maxseg / LPF_GROUP_SEGS + 1);
+        float4 *ml; CK(hipMalloc(&ml, (size_t)N * 16)); P.mlist = ml;
+    }
 
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -150,54 +157,6 @@ int main(int argc, char **argv)
         timeit("ref copy16->8+4 r4", [&](int b) { hipLaunchKernelGGL(ref_copy_16_8_4<4>, dim3(nb4), dim3(256), 0, s, pts[b], uv[b], lab[b], N); }, 28.0 * N);
         timeit("ref copy16->8+4 r8", [&](int b) { hipLaunchKernelGGL(ref_copy_16_8_4<8>, dim3(nb8), dim3(256), 0, s, pts[b], uv[b], lab[b], N); }, 28.0 * N);
         CK(hipFree(o4));
-    }
-    {   // ---- K2 / scan ablations on a real K1 result (F = 1) ----
-        const int seg_pts = LPF_SEG_QUANTUM, nseg = (N + seg_pts - 1) / seg_pts;
-        LpfFrame fr; memset(&fr, 0, sizeof fr); fr.N = N; fr.nseg = nseg; fr.B = 32;
-        uint4 *pre; unsigned *ftot, *cnt; long long *vidx, *iidx; double *boxp; float *boxq;
-        CK(hipMalloc(&pre, LPF_TAB_GROUPS * maxseg * 16)); CK(hipMalloc(&ftot, LPF_TAB_ROWS * 4)); CK(hipMalloc(&cnt, 8 * 32 * 4));
-        CK(hipMemset(cnt, 0, 8 * 32 * 4));
-        CK(hipMalloc(&vidx, (size_t)N * 8)); CK(hipMalloc(&iidx, (size_t)N * 8));
-        std::vector<double> hbp(32 * 16, 0.0); std::vector<float> hbq(32 * 8, 0.f);
-        for (int b = 0; b < 32; ++b) {   // axis-aligned car-sized boxes (4.4 x 2.0 x 1.65 m) inside the frustum
-            double *o = &hbp[b * 16]; const double cx = 6 + (b % 8) * 5, cy = -12 + (b / 8) * 7, cz = -1.8;
-            o[0] = cx; o[1] = cy; o[2] = cz; o[3] = 4.4; o[6] = 4.4 * 4.4; o[8] = 2.0; o[10] = 4.0; o[13] = 1.65; o[14] = 1.65 * 1.65; o[15] = 1;
-            float *q = &hbq[b * 8]; q[0] = cx - 0.01f; q[1] = cy - 0.01f; q[2] = cz - 0.01f; q[4] = cx + 4.41f; q[5] = cy + 2.01f; q[6] = cz + 1.66f;
-        }
-        CK(hipMalloc(&boxp, hbp.size() * 8)); CK(hipMalloc(&boxq, hbq.size() * 4));
-        CK(hipMemcpy(boxp, hbp.data(), hbp.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(boxq, hbq.data(), hbq.size() * 4, hipMemcpyHostToDevice));
-        unsigned long long *cand; { std::vector<unsigned long long> hc(44 * 12, 0xFFFFFFFFull); CK(hipMalloc(&cand, hc.size() * 8)); CK(hipMemcpy(cand, hc.data(), hc.size() * 8, hipMemcpyHostToDevice)); }
-        fr.cand_off = 0; fr.cand_words = 1; P.cand = cand; P.cell_shift = 5; P.cell_w = 44;
-        P.seg_pts = seg_pts; P.nseg_total = nseg; P.nseg_cap = nseg; P.frame0 = fr; P.oriented = 1;
-        P.seg_pre = pre; P.frame_tot = ftot; P.cnt = cnt; P.valid_idx = vidx; P.inst_idx = iidx; P.inst_cap = N; P.boxp = boxp; P.boxq = boxq;
-        float4 *ml; CK(hipMalloc(&ml, (size_t)N * 16)); P.mlist = ml; P.tile_pts = 1024;
-        P.pts = pts[0]; P.uv = uv[0]; P.label_bits = lab[0];
-        launch_t<4, LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE>(P, nseg, s);
-        CK(hipStreamSynchronize(s));
-        auto timeit2 = [&](const char *name, auto fn) {
-            for (int it = 0; it < 10; ++it) fn();
-            CK(hipStreamSynchronize(s)); CK(hipEventRecord(e0, s));
-            for (int it = 0; it < 100; ++it) fn();
-            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%-34s %10.2f us\n", name, 1e3 * ms / 100);
-        };
-        // the scan zeroes seg_tab: time it on the (then empty) table, structure is identical
-        if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P);
-        timeit2("scan_segments (1 frame)", [&]() { if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P); });
-        // rebuild a real prefix table for K2
-        launch_t<4, LPF_F_X4 | LPF_F_NTLOAD | LPF_F_NTSTORE>(P, nseg, s);
-        if (nseg <= 1024) hipLaunchKernelGGL((lpf_scan_segments_t<3>), dim3(1), dim3(LPF_BLOCK), 0, s, P); else hipLaunchKernelGGL((lpf_scan_segments_t<0>), dim3(1), dim3(LPF_BLOCK), 0, s, P);
-        CK(hipStreamSynchronize(s));
-        const int nb2 = (nseg + LPF_K2_WAVES - 1) / LPF_K2_WAVES;
-        timeit2("k2 full", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<0u>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOVALID", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOVALID>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOLIST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOLIST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOVALID NOLIST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOVALID | LPF_F2_LAB_NOLIST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOBOX", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOINST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOINST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        timeit2("k2 NOBOX NOINST", [&]() { hipLaunchKernelGGL((lpf_k2_lists_t<LPF_F2_LAB_NOBOX | LPF_F2_LAB_NOINST>), dim3(nb2), dim3(LPF_BLOCK), 0, s, P); });
-        P.valid_idx = nullptr; P.inst_idx = nullptr; P.boxp = nullptr; P.boxq = nullptr; P.cnt = nullptr;
     }
     {   // ---- occupancy sweep: how many resident blocks per CU does the kernel need to hold its bandwidth?  A dynamic-LDS
         //      pad caps the blocks a CU admits (160 KB / pad); tail kernels running beside K1 take wave slots the same way.
