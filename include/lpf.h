@@ -119,7 +119,8 @@ int  lpf_sync(lpf_ctx *ctx);
  * the streaming kernel already queued; the mask tensor must then be complete when lpf_set_masks_* is
  * called (the side stream does not wait for the caller's stream).  With any of them on, the outputs of a run are
  * complete after lpf_sync() (or lpf_release_to_stream()), not after the caller's stream alone, and the caller's
- * output buffers of a run must stay untouched until then.  0 = off (default). */
+ * output buffers of a run must stay untouched until then.  The label images rotate with the scratch sets: call
+ * lpf_set_masks_* before every lpf_run* while a pipelined mode is on.  0 = off (default). */
 int  lpf_set_pipelined(lpf_ctx *ctx, int on);
 /* Confine the internal side streams of the pipelined mode to side_cus compute units (a multiple of 8: the same
  * share of each of the 8 XCDs; 0 = no confinement), so the tail kernels do not take issue slots from the

@@ -889,7 +889,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
     P.label_img = (M > 0) ? S.label_cur : nullptr;
-    if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "masks were set for another scratch set (toggle pipelining only with masks re-set)");
+    if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
@@ -978,7 +978,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (fused && !small) P.tile_pts = 2048;
     const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
     const int lb = (M > 0) ? S.label_bytes : 4;
-    const int ntail = nblk * (count_boxes ? 2 : 1);
+    const bool want_lists = out->valid_idx || out->inst_idx;
+    const int ntail = nblk * ((count_boxes ? 1 : 0) + (want_lists ? 1 : 0));      // no lists wanted and no boxes: no tail blocks at all
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if ((nk1 > 0 || fused) && c->profiling && c->ev_used < (1u << 16)) {
         if (c->ev.size() < 2 * (c->ev_used + 1)) {
@@ -1054,7 +1055,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
         LPF_HIP(c, hipGetLastError());
     }
-    {
+    if (ntail > 0) {
         if (pre_scan) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
         else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
         LPF_HIP(c, hipGetLastError());

@@ -913,7 +913,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
     LpfTailCountLds &LC = *reinterpret_cast<LpfTailCountLds *>(s_raw);
     const int tid = threadIdx.x, wave = lpf_wave();
-    const int ncount = P.count_boxes ? (P.count_split ? 4 * P.nblk : P.nblk) : 0;
+    const int ncount = P.count_boxes ? (P.count_split ? 4 * P.nblk : P.nblk) : 0;   // (the list blocks follow; none when no list is wanted)
     const bool count_role = tb < ncount;
     const int te = count_role ? (P.count_split ? tb >> 2 : tb) : tb - ncount;
     const int2 ent = P.blks[te];                           // {first segment, frame << 3 | segments}
