@@ -281,8 +281,26 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             if not ok:
                 raise SystemExit("bench secondary configs[3]: GPU result differs from the golden vectors of frame 100")
             dt = time_steps(torch, dev, [fn], 500, 30, sync)
+
+            def fused_loop(step_fn, check):
+                """the same step in a loop under the software-pipelined mode (a stream of batches: throughput, not latency)"""
+                ctx.set_pipelined("fused")
+                for _ in range(3):
+                    step_fn()
+                ctx.sync()
+                check()
+                t = time_steps(torch, dev, [step_fn], 500, 30, lambda: (ctx.sync(), sync()))
+                ctx.set_pipelined(False)
+                return t
+
+            def check3():
+                cm_ = o["count_mb"].cpu().numpy().reshape(F, M, B)
+                if not all(np.array_equal(cm_[f], g["count_mb_rect5_d50"]) for f in range(F)):
+                    raise SystemExit("bench secondary configs[3], pipelined: GPU result differs from the golden vectors of frame 100")
+            dtf = fused_loop(fn, check3)
             out["configs3_20_real_frames_one_batch"] = {
                 "points_per_s": F * n / dt, "us_per_step": 1e6 * dt, "frames": F, "points_per_frame": n, "masks": M, "boxes": B,
+                "us_per_step_software_pipelined": 1e6 * dtf, "points_per_s_software_pipelined": F * n / dtf,
                 "checked": "count_mb, n_valid, valid_idx of every frame == tests/golden/frame_0000000100.npz (reference functions)"}
             # ... and the same frame alone (configs[1]): launch-bound
             o1 = make_outputs(torch, dev, n, 1, n, M, B, SUMMARY_DTYPE.itemsize)
@@ -293,7 +311,13 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             if not np.array_equal(o1["count_mb"].cpu().numpy().reshape(M, B), g["count_mb_rect5_d50"]):
                 raise SystemExit("bench secondary configs[1]: GPU result differs from the golden vectors of frame 100")
             dt1 = time_steps(torch, dev, [fn1], 1000, 30, sync)
+
+            def check1():
+                if not np.array_equal(o1["count_mb"].cpu().numpy().reshape(M, B), g["count_mb_rect5_d50"]):
+                    raise SystemExit("bench secondary configs[1], pipelined: GPU result differs from the golden vectors of frame 100")
+            dt1f = fused_loop(fn1, check1)
             out["configs1_frame100_device_resident"] = {"points_per_s": n / dt1, "us_per_frame": 1e6 * dt1, "points": n,
+                                                        "us_per_frame_in_a_software_pipelined_stream": 1e6 * dt1f,
                                                         "checked": "count_mb == golden"}
 
     # ---- configs[4]: stream of 1 M-point frames + 8 masks eroded once, H2D + kernels + D2H in one hipGraph per frame ----

@@ -667,6 +667,12 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!c) return LPF_ERR_ARG;
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
+    // pipelined modes: the tail of a run already queued / still owed counts boxes with the OLD camera's candidate grid
+    if (!c->capturing && (c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending)) {
+        if (use_device(c)) return LPF_ERR_HIP;
+        int rc_ = sync_all(c);
+        if (rc_) return rc_;
+    }
     if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->box_F = 0; c->box_off.clear(); }   // label images and the
                                                                        // candidate grid are per W x H: set masks / boxes again
     memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
@@ -750,9 +756,11 @@ int lpf_set_boxes_ex(lpf_ctx *c, const double *corners, int on_device, const int
     const int Btot = box_off[F];
     if (Btot > 0 && !corners) { c->box_F = 0; return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL"); }
     c->have_enabled = false;
-    if (Btot > 0)
+    if (Btot > 0) {
         LPF_HIP(c, hipMemcpyAsync(c->box_corners.p, corners, (size_t)Btot * 24 * sizeof(double),
                                   on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));      // the caller's host buffer is free on return
+    }
     return launch_box_setup(c);
 }
 
@@ -793,7 +801,7 @@ int lpf_set_boxes_cam0(lpf_ctx *c, const double *corners_cam0, int on_device, co
     if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, c->box_corners.p, nb * 192, back, c->stream));
     if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, aux + o_bb, nb * 32, back, c->stream));
     if (front) LPF_HIP(c, hipMemcpyAsync(front, aux + o_fr, nb * 4, back, c->stream));
-    if (!on_device && (visible || corners_velo || bbox2d || front)) LPF_HIP(c, hipStreamSynchronize(c->stream));
+    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));          // host buffers (in and out) are the caller's again
     return LPF_OK;
 }
 
@@ -896,7 +904,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
-    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0; P.count_split = 0;
+    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;

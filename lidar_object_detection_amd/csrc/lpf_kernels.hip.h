@@ -87,7 +87,6 @@ struct LpfParams {
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
                                  // bits} of its masked points in point order (nothing gathers from the cloud later)
     int count_boxes;             // 1: the tail launch carries the box-count blocks
-    int count_split;             // 1: a box-count block is ONE segment, a quarter of its rows per wave (small launches)
     int tile_pts;                // points per K1 tile of this launch (4 waves)
 };
 
@@ -684,11 +683,9 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
 #define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
 #define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS (their float bounds: 64)
 
-// part < 0: the wave takes the whole segment; part = 0..3: its quarter of the segment's rows (small launches: a block per
-// segment, so that a segment lying on a car -- hundreds of masked points -- is four short chains instead of one long one)
 __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
                                                   unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
-                                                  const double *s_tk, const int part)
+                                                  const double *s_tk)
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -707,13 +704,8 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
         if (lane >= o) im += tm;
     }
     const unsigned mbase = im - cm;
-    unsigned e_lo = 0, L = lpf_rl(im, 63);                  // entries [e_lo, L) of the segment are this wave's
-    if (part >= 0) {
-        const int qr = rps >> 2;                           // rows per quarter
-        e_lo = lpf_rl(mbase, part * qr);
-        L = lpf_rl(im, part * qr + qr - 1);
-    }
-    if (L == e_lo) return;
+    const unsigned L = lpf_rl(im, 63);
+    if (L == 0) return;
     const int B = fr.B;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
@@ -746,7 +738,7 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
             }
         }
     };
-    for (unsigned e0 = e_lo; e0 < L; e0 += 64) {
+    for (unsigned e0 = 0; e0 < L; e0 += 64) {
         const unsigned e = e0 + lane;
         const bool act = e < L;
         // row of entry e: the first row whose inclusive prefix exceeds e (im is non-decreasing over the lanes)
@@ -906,17 +898,16 @@ struct LpfTailCountLds {
 
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
 
-// one tail block: the first nblk (4 nblk when split) count boxes (when there are any: the longer chain goes first), the next nblk build lists
+// one tail block: the first nblk count boxes (when there are any: the longer chain goes first), the next nblk build lists
 template <bool PRE>
 __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb, char *s_raw)
 {
     LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
     LpfTailCountLds &LC = *reinterpret_cast<LpfTailCountLds *>(s_raw);
     const int tid = threadIdx.x, wave = lpf_wave();
-    const int ncount = P.count_boxes ? (P.count_split ? 4 * P.nblk : P.nblk) : 0;   // (the list blocks follow; none when no list is wanted)
+    const int ncount = P.count_boxes ? P.nblk : 0;          // (the list blocks follow; none when no list is wanted)
     const bool count_role = tb < ncount;
-    const int te = count_role ? (P.count_split ? tb >> 2 : tb) : tb - ncount;
-    const int2 ent = P.blks[te];                           // {first segment, frame << 3 | segments}
+    const int2 ent = P.blks[count_role ? tb : tb - ncount]; // {first segment, frame << 3 | segments}
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
     if (!count_role) {
@@ -934,11 +925,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
             else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
         }
         __syncthreads();
-        if (P.count_split) {                                // the block's four waves share one segment
-            if ((tb & 3) < nw) lpf_boxcount_wave(P, fr, ent.x + (tb & 3), LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, wave);
-        } else if (wave < nw) {
-            lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, -1);
-        }
+        if (wave < nw) lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
         __syncthreads();
         unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
         if (lds_cnt) {

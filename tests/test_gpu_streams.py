@@ -129,3 +129,65 @@ def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
         ctx.sync()
         _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
         del make
+
+
+def test_software_pipelined_mode_across_state_changes(calib):
+    """lpf_set_pipelined(2): the tail of a run rides in the NEXT run's launch and its summaries in the one after.  Whatever
+    changes between two runs -- camera window, boxes, masks and their count, batch shape, launch geometry -- the owed work
+    must be finished with the state it was queued under.  Nothing is synchronised by the test until every run is queued."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    plan = [  # (sizes per frame, masks, boxes, depth max, geometry)
+        ([40_000, 9_000], 4, 6, 30.0, "auto"), ([40_000, 9_000], 4, 6, 30.0, "auto"), ([40_000, 9_000], 4, 6, 50.0, "auto"),
+        ([25_000], 7, 3, 50.0, "auto"), ([25_000], 7, 11, 50.0, "large"), ([70_001, 5, 300], 2, 11, 20.0, "small"),
+        ([70_001, 5, 300], 2, 11, 20.0, "large-scan"), ([12_345], 0, 0, 20.0, "auto"), ([12_345], 3, 5, 20.0, "auto")]
+    runs = []
+    with LpfContext(0) as ctx:
+        ctx.set_pipelined("fused")
+        for k, (sizes, M, Bx, dmax, geo) in enumerate(plan):
+            scenes = [S.scene(max(n, 1), n_masks=max(M, 1), n_boxes=max(Bx, 1), seed=300 + 10 * k + f) for f, n in enumerate(sizes)]
+            F, n = len(sizes), int(sum(sizes))
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            pts = torch.from_numpy(np.concatenate([sc["points"][:m] for sc, m in zip(scenes, sizes)])).to(dev)
+            o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                     valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, max(sizes)), dtype=torch.int64, device=dev),
+                     count_mb=torch.zeros(max(F * M * Bx, 1), dtype=torch.int32, device=dev),
+                     summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+            masks = torch.from_numpy(np.stack([sc["masks"][:M] for sc in scenes])).to(dev) if M else None
+            torch.cuda.synchronize(dev)                     # inputs are ready (the context runs on its own stream)
+            ctx.set_geometry(geo)
+            ctx.set_camera(T, K, W, H, 0.0, dmax)
+            if M:
+                ctx.set_masks(masks)
+            else:
+                ctx.clear_masks()
+            if Bx:
+                ctx.set_boxes([sc["corners_velo"][:Bx] for sc in scenes])
+            else:
+                ctx.clear_boxes()
+            ctx.run_device(pts, off, inst_cap=max(sizes), **o)
+            runs.append((scenes, sizes, M, Bx, dmax, off, o, pts, masks))
+        ctx.sync()
+    for scenes, sizes, M, Bx, dmax, off, o, pts, masks in runs:
+        F = len(sizes)
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+        vidx, iidx, cmb = o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy(), o["count_mb"].cpu().numpy()
+        boff = 0
+        for f, (sc, nf) in enumerate(zip(scenes, sizes)):
+            a = int(off[f])
+            limg = orc.pack_masks(sc["masks"][:M], 0, H, W) if M else None
+            ref = orc.run(sc["points"][:nf], T, K, W, H, 0.0, dmax, label_img=limg, M=M, corners=sc["corners_velo"][:Bx] if Bx else None,
+                          want_float=False)
+            assert int(sm[f]["n_valid"]) == ref["n_valid"]
+            assert np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"])
+            assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"])
+            for m in range(M):
+                lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+                assert np.array_equal(iidx[f, lo:hi], ref["inst_lists"][m])
+            if M and Bx:
+                assert np.array_equal(cmb[M * boff:M * (boff + Bx)].reshape(M, Bx), ref["count_mb"])
+                assert np.array_equal(sm[f]["best_box"][:M], ref["best_box"]) and np.array_equal(sm[f]["best_cnt"][:M], ref["best_cnt"])
+            boff += Bx
