@@ -973,7 +973,7 @@ struct LpfStepLayout {
 };
 
 template <int ROWS, unsigned FL, typename LT, bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y)
+__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
