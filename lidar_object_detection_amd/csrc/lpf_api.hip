@@ -1012,8 +1012,10 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         const int nk1_pad = (nk1 + 7) & ~7;
         Y.nper = (Y.ntail + 7) / 8;
         Y.kper = 8;
-        if (Y.nper > 0) {                                  // spread the tail blocks over the first ~90 % of the tiles
-            const long long k = ((long long)nk1_pad * 9 / 10 / 8) / Y.nper;     // (25 / 50 / 100 % measured within 2 us of this)
+        if (Y.nper > 0) {                                  // spread the tail blocks over the first two thirds of the tiles (same box,
+            // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5:
+            // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)
+            const long long k = ((long long)nk1_pad * 13 / 20 / 8) / Y.nper;
             Y.kper = (int)(k < 1 ? 1 : k) * 8;
         }
         const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
