@@ -19,7 +19,7 @@
 // shorter blocks and list waves: a single real frame is 107 segments instead of 27).
 #define LPF_SMALL_LAUNCH (4ll << 20)
 
-static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_k3_finalize");
+static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_finalize_frame");
 
 namespace {
 
@@ -947,7 +947,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         P.summary = out->summary;
     }
 #undef LPF_OUTBUF
-    if (M > 0) {                         // K1 -> K2 hand-off of the masked points (sparse writes into N slots)
+    if (M > 0) {                         // K1 -> tail hand-off of the masked points (sparse writes into N slots)
         if ((rc = reserve(c, S.mlist, n * 16))) return rc;
         P.mlist = (float4 *)S.mlist.p;
     }

@@ -198,7 +198,7 @@ __device__ __forceinline__ void lpf_project_point_mem(const double *__restrict__
 template <int ROWS, unsigned FL, typename LT>
 __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, unsigned *s_cnt)
 {
-    // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a K2 segment
+    // one block = one tile of 256*ROWS points; seg_pts / tile tiles share a segment (= one list wave of the tail)
     constexpr int TILE = LPF_BLOCK * ROWS;
     static_assert(LPF_SEG_QUANTUM % TILE == 0 && (LPF_SEG_SMALL % TILE == 0 || ROWS >= 8), "tiles must divide segments (8-row and larger tiles: large geometry only)");
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
@@ -291,7 +291,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
             const unsigned long long mb = __ballot(l != 0);
             if (lane == r) { myv = vb; mym = mb; }
             // the wave's masked points {x, y, z, label}, compacted in point order at the wave's own
-            // first slots: K2 reads them back coalesced instead of gathering from the cloud
+            // first slots: the tail reads them back in runs instead of gathering from the cloud
             if (l && P.mlist && !(FL & LPF_F_LAB_NOSTORE))
                 P.mlist[fr.pt_off + (wbase - lane) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
                     make_float4(p[r].x, p[r].y, p[r].z, __uint_as_float(l));
@@ -498,8 +498,6 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments(const LpfParams P
 // waves per block, no block barriers.  From the ballots K1 left it writes the stable index lists:
 //   valid_idx (+ the compact uv_valid / label_valid)                                    (V3:585, 590-592)
 //   inst_idx, one list per mask                                                       (V3:225-228)
-//   mdense: the frame's masked points {x, y, z, label bits}, densely, in point order -- what the
-//           box-count kernel reads with every lane busy (K1 leaves them per wave, at that wave's slot).
 // Where a segment's entries start in its frame's lists is derived by the wave itself from the three
 // levels of counters K1's tiles added into (segment, group of 64 segments, frame): two masked wave sums
 // per counter, no scan kernel in between (PRE = true: frames with more than 64 groups, see lpf_scan_segments).
