@@ -935,9 +935,10 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     }
 }
 
-// 8 blocks per CU (all of a 16 M-point step's ~2000 blocks resident at once): <= 64 VGPRs, <= 80 SGPRs, <= 20 KB LDS
+// 7 blocks per CU (72 VGPRs: no spills -- at 8 the kernel spills six registers per thread to scratch, which is HBM traffic too:
+// 111 vs 112 us per serial step); 61 SGPRs, 16.7 KB LDS
 template <bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     lpf_tail_block<PRE>(P, (int)blockIdx.x, s_raw);
