@@ -78,3 +78,62 @@ def test_fuzz_against_oracle(seed, form, calib):
             assert np.array_equal(a, b), (seed, form, f)
         for k in ("depth", "uf", "vf"):
             assert np.array_equal(r[k], o[k], equal_nan=True), (seed, form, f, k)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24")) // 2))
+def test_fuzz_software_pipelined_device_mode(seed, calib):
+    """The same random cases through device mode under lpf_set_pipelined(2), three consecutive cases per context with nothing
+    synchronised in between: the tail of case k rides in the launch of case k+1 (another shape, other masks and boxes), its
+    summaries in the launch of case k+2."""
+    import torch
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    dev = torch.device("cuda", 0)
+    base = int(os.environ.get("LPF_FUZZ_SEED_BASE", "1000"))
+    cases = [_case(base + 3 * seed + j, calib) for j in range(3)]
+    held = []
+    with LpfContext(0) as ctx:
+        ctx.set_pipelined("fused")
+        for T, K, W, H, dmax, oriented, M, frames, masks, boxes in cases:
+            F = len(frames)
+            sizes = [len(p) for p in frames]
+            n = int(sum(sizes))
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            cap = max(max(sizes), 1) * max(M, 1)          # a point may be in every mask: room for all lists of a frame
+            Btot = int(sum(len(b) for b in boxes))
+            pts = torch.from_numpy(np.concatenate(frames).astype(np.float32).reshape(-1, 4)).to(dev) if n else torch.zeros((1, 4), dtype=torch.float32, device=dev)
+            o = dict(uv=torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev), label_bits=torch.empty(max(n, 1), dtype=torch.int32, device=dev),
+                     valid_idx=torch.empty(max(n, 1), dtype=torch.int64, device=dev), inst_idx=torch.empty((F, cap), dtype=torch.int64, device=dev),
+                     count_mb=torch.zeros(max(M * Btot, 1), dtype=torch.int32, device=dev),
+                     summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+            mt = torch.from_numpy(np.stack(masks)).to(dev) if M else None
+            torch.cuda.synchronize(dev)
+            ctx.set_camera(T, K, W, H, 0.0, dmax)
+            if M:
+                ctx.set_masks(mt)
+            else:
+                ctx.clear_masks()
+            ctx.set_boxes(boxes, oriented=oriented)
+            ctx.run_device(pts, off, inst_cap=cap, **o)
+            held.append((o, pts, mt, off, sizes))
+        ctx.sync()
+    for (T, K, W, H, dmax, oriented, M, frames, masks, boxes), (o, pts, mt, off, sizes) in zip(cases, held):
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+        uv, lab = o["uv"].cpu().numpy(), o["label_bits"].cpu().numpy().view(np.uint32)
+        vidx, iidx, cmb = o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy(), o["count_mb"].cpu().numpy()
+        boff = 0
+        for f in range(len(frames)):
+            a, b = int(off[f]), int(off[f + 1])
+            labimg = orc.pack_masks(masks[f], 0, H, W) if M else None
+            ref = orc.run(frames[f], T, K, W, H, 0.0, dmax, label_img=labimg, M=M, corners=boxes[f], oriented=oriented, want_float=False)
+            assert np.array_equal(uv[a:b, 0], ref["u"]) and np.array_equal(uv[a:b, 1], ref["v"]), (seed, f)
+            assert np.array_equal(lab[a:b], ref["label_bits"]), (seed, f)
+            assert int(sm[f]["n_valid"]) == ref["n_valid"] and np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"]), (seed, f)
+            assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"]), (seed, f)
+            for m in range(M):
+                lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+                assert np.array_equal(iidx[f, lo:hi], ref["inst_lists"][m]), (seed, f, m)
+            B = len(boxes[f])
+            if M and B:
+                assert np.array_equal(cmb[M * boff:M * (boff + B)].reshape(M, B), ref["count_mb"]), (seed, f)
+            assert np.array_equal(sm[f]["best_box"][:M], ref["best_box"]) and np.array_equal(sm[f]["best_cnt"][:M], ref["best_cnt"]), (seed, f)
+            boff += B
