@@ -18,6 +18,9 @@
 // Points per launch up to which a run uses the small geometry: 512-point K1 tiles and 1024-point segments (more,
 // shorter blocks and list waves: a single real frame is 107 segments instead of 27).
 #define LPF_SMALL_LAUNCH (4ll << 20)
+// Tail blocks (of four 1024-point segments) up to which the wide form of the tail runs (measured on copies of sample frame 100:
+// 1 frame = 27 blocks 22.5 vs 25.9 us; 6 frames 29.8 vs 32.8; 8 frames 34.4 vs 35.7; 20 frames = 535 blocks 55.4 vs 49.0 us)
+#define LPF_WIDE_BELOW 220
 
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_finalize_frame");
 
@@ -1066,8 +1069,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
     }
     if (ntail > 0) {
-        if (pre_scan) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
-        else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+        if (small && count_boxes && nblk <= LPF_WIDE_BELOW) {   // a frame or a few, dense real segments: the box-count blocks share their chunks over 16 waves
+            if (pre_scan) hipLaunchKernelGGL((lpf_tail_wide_t<true>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
+            else hipLaunchKernelGGL((lpf_tail_wide_t<false>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
+        } else {
+            if (pre_scan) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+            else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+        }
         LPF_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(lpf_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);

@@ -681,34 +681,39 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
 #define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
 #define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS (their float bounds: 64)
 
-__device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
-                                                  unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
-                                                  const double *s_tk)
+// row prefixes of a segment's masked ballots: lane r -> entries in rows 0..r (im) and before row r (mbase); returns the total
+__device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned &im, unsigned &mbase)
 {
     const int lane = lpf_lane();
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const int rps = P.seg_pts >> 6;
-    const int k = sid - fr.seg_off;
     unsigned long long mb = 0;
     if (lane < rps) mb = P.mbal[(size_t)sid * rps + lane];
-    const int seg_start = k * P.seg_pts;
+    const int seg_start = (sid - fr.seg_off) * P.seg_pts;
     const int nrows = (min(seg_start + P.seg_pts, fr.N) - seg_start + 63) >> 6;
     if (lane >= nrows) mb = 0;                             // rows K1 never wrote
     const unsigned cm = __popcll(mb);
-    unsigned im = cm;
+    im = cm;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {                     // inclusive scan over the row counts
         const unsigned tm = __shfl_up(im, o);
         if (lane >= o) im += tm;
     }
-    const unsigned mbase = im - cm;
-    const unsigned L = lpf_rl(im, 63);
-    if (L == 0) return;
+    mbase = im - cm;
+    return lpf_rl(im, 63);
+}
+
+// one chunk of 64 masked points (entries e0 .. e0+63 of segment sid, L in all) against the frame's candidate boxes
+__device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFrame &fr, const int sid, const unsigned im, const unsigned mbase,
+                                                const unsigned L, const unsigned e0, float4 *s_pt, unsigned *qq, unsigned *s_cnt,
+                                                const bool lds_cnt, const float4 *s_bq, const double *s_bp, const double *s_tk)
+{
+    const int lane = lpf_lane();
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int B = fr.B;
     const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
     const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
     unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + (size_t)(sid - fr.seg_off) * P.seg_pts;
     const int rows_per_wave = P.tile_pts >> 8;
     const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
     auto exact = [&](int count) {
@@ -736,64 +741,72 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
             }
         }
     };
-    for (unsigned e0 = 0; e0 < L; e0 += 64) {
-        const unsigned e = e0 + lane;
-        const bool act = e < L;
-        // row of entry e: the first row whose inclusive prefix exceeds e (im is non-decreasing over the lanes)
-        int row = 0;
+    const unsigned e = e0 + lane;
+    const bool act = e < L;
+    // row of entry e: the first row whose inclusive prefix exceeds e (im is non-decreasing over the lanes)
+    int row = 0;
 #pragma unroll
-        for (int st = 32; st > 0; st >>= 1) {
-            const unsigned v = (unsigned)__shfl((int)im, row + st - 1);
-            if (v <= e) row += st;
-        }
-        row = min(row, 63);
-        const int first_row = (row >> rpw_shift) << rpw_shift;
-        const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act) p = mseg[first_row * 64 + (int)(e - wb)];
-        __builtin_amdgcn_wave_barrier();
-        s_pt[lane] = p;                                     // .w carries the label bits (0 for idle lanes)
-        __builtin_amdgcn_wave_barrier();
-        int qn = 0;                                         // wave-uniform queue length
-        int cell = 0;
-        if (act) {                                          // same arithmetic as K1 => the same pixel; masked => valid => in range
-            double uf, vf, d;
-            lpf_project_point_mem(s_tk, p.x, p.y, p.z, uf, vf, d);
-            cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
-        }
-        const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
-        for (int w = 0; w < fr.cand_words; ++w) {
-            unsigned long long mset = act ? cg[w] : 0ull;
-            while (__any(mset != 0ull)) {
-                const bool has = mset != 0ull;
-                const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
-                mset &= mset - 1ull;
-                bool near = false;
-                if (has) {
-                    float4 lo, hi;
-                    if (b < 64) { lo = s_bq[2 * b]; hi = s_bq[2 * b + 1]; }
-                    else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
-                    near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
-                }
-                const unsigned long long bal = __ballot(near);
-                if (!bal) continue;
-                if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
-                qn += __popcll(bal);
-                if (qn >= 64) {
-                    __builtin_amdgcn_wave_barrier();
-                    exact(64);
-                    const unsigned rest = qq[64 + lane];
-                    __builtin_amdgcn_wave_barrier();
-                    qq[lane] = rest;
-                    qn -= 64;
-                    __builtin_amdgcn_wave_barrier();
-                }
+    for (int st = 32; st > 0; st >>= 1) {
+        const unsigned v = (unsigned)__shfl((int)im, row + st - 1);
+        if (v <= e) row += st;
+    }
+    row = min(row, 63);
+    const int first_row = (row >> rpw_shift) << rpw_shift;
+    const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) p = mseg[first_row * 64 + (int)(e - wb)];
+    __builtin_amdgcn_wave_barrier();
+    s_pt[lane] = p;                                         // .w carries the label bits (0 for idle lanes)
+    __builtin_amdgcn_wave_barrier();
+    int qn = 0;                                             // wave-uniform queue length
+    int cell = 0;
+    if (act) {                                              // same arithmetic as K1 => the same pixel; masked => valid => in range
+        double uf, vf, d;
+        lpf_project_point_mem(s_tk, p.x, p.y, p.z, uf, vf, d);
+        cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
+    }
+    const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
+    for (int w = 0; w < fr.cand_words; ++w) {
+        unsigned long long mset = act ? cg[w] : 0ull;
+        while (__any(mset != 0ull)) {
+            const bool has = mset != 0ull;
+            const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
+            mset &= mset - 1ull;
+            bool near = false;
+            if (has) {
+                float4 lo, hi;
+                if (b < 64) { lo = s_bq[2 * b]; hi = s_bq[2 * b + 1]; }
+                else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
+                near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
+            }
+            const unsigned long long bal = __ballot(near);
+            if (!bal) continue;
+            if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
+            qn += __popcll(bal);
+            if (qn >= 64) {
+                __builtin_amdgcn_wave_barrier();
+                exact(64);
+                const unsigned rest = qq[64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                qq[lane] = rest;
+                qn -= 64;
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        exact(qn);
-        __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
+    exact(qn);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// a wave takes a whole segment (big sparse launches: a chunk or so per segment)
+__device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
+                                                  unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
+                                                  const double *s_tk)
+{
+    unsigned im, mbase;
+    const unsigned L = lpf_count_rows(P, fr, sid, im, mbase);
+    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, lds_cnt, s_bq, s_bp, s_tk);
 }
 
 // ------------------------------------------------------------------------------------
@@ -942,6 +955,78 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     lpf_tail_block<PRE>(P, (int)blockIdx.x, s_raw);
+}
+
+// ------------------------------------------------------------------------------------
+// TAIL, wide form (small launches: a frame or a few): the same two roles with 16 waves per block.  A real scan is dense
+// in places -- consecutive points are neighbours in space, so a segment lying on a car holds hundreds of masked points
+// while its neighbours hold none -- and with a frame's worth of segments the launch is as long as its heaviest wave.
+// Here the box-count block's 16 waves SHARE the chunks (64 masked points) of the block's four segments: waves 0..3
+// publish their segment's row prefixes in LDS, then chunk c goes to wave c mod 16.  The list blocks use four of the
+// waves (a segment each), the others leave at once.  Same results as lpf_tail_t.
+// ------------------------------------------------------------------------------------
+#define LPF_WIDE_WAVES 16
+
+struct LpfTailWideLds {
+    float4 pt[LPF_WIDE_WAVES][64];
+    unsigned q[LPF_WIDE_WAVES][128];
+    unsigned cnt[LPF_BC_LDSCNT];
+    float4 bq[2 * 64];
+    double bp[LPF_BC_LDSB * 16];
+    double tk[21];
+    unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];
+};
+
+template <bool PRE>
+__global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const LpfParams P)
+{
+    __shared__ __attribute__((aligned(16))) char s_raw[sizeof(LpfTailWideLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailWideLds) : sizeof(LpfTailListsLds)];
+    LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
+    LpfTailWideLds &LC = *reinterpret_cast<LpfTailWideLds *>(s_raw);
+    const int tid = threadIdx.x, lane = lpf_lane(), wave = tid >> 6, tb = (int)blockIdx.x;
+    const int ncount = P.count_boxes ? P.nblk : 0;
+    const bool count_role = tb < ncount;
+    const int2 ent = P.blks[count_role ? tb : tb - ncount];
+    const int f = ent.y >> 3, nw = ent.y & 7;
+    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    if (!count_role) {
+        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
+        return;
+    }
+    const int MB = P.M * fr.B;
+    const bool lds_cnt = MB <= LPF_BC_LDSCNT;
+    if (lds_cnt) for (int i = tid; i < MB; i += 64 * LPF_WIDE_WAVES) LC.cnt[i] = 0u;
+    {
+        const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
+        const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
+        if (tid < 2 * min(fr.B, 64)) LC.bq[tid] = boxq[tid];
+        for (int i = tid; i < min(fr.B, LPF_BC_LDSB) * 16; i += 64 * LPF_WIDE_WAVES) LC.bp[i] = boxp[i];
+        if (tid < 12) LC.tk[tid] = P.T[tid];
+        else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
+    }
+    if (wave < LPF_LISTS_WAVES) {                           // the block's (up to) four segments: row prefixes -> LDS
+        unsigned im = 0, mbase = 0, L = 0;
+        if (wave < nw) L = lpf_count_rows(P, fr, ent.x + wave, im, mbase);
+        LC.im[wave][lane] = im; LC.mbase[wave][lane] = mbase;
+        if (lane == 0) LC.L[wave] = L;
+    }
+    __syncthreads();
+    const unsigned L0 = LC.L[0], L1 = LC.L[1], L2 = LC.L[2], L3 = LC.L[3];
+    const int c0 = (int)((L0 + 63) >> 6), c1 = (int)((L1 + 63) >> 6), c2 = (int)((L2 + 63) >> 6), c3 = (int)((L3 + 63) >> 6);
+    for (int c = wave; c < c0 + c1 + c2 + c3; c += LPF_WIDE_WAVES) {      // wave-uniform: chunk c of the block -> (segment, chunk of it)
+        int sg = 0, cc = c;
+        if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
+        lpf_count_chunk(P, fr, ent.x + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
+                        LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
+    }
+    __syncthreads();
+    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    if (lds_cnt) {
+        for (int i = tid; i < MB; i += 64 * LPF_WIDE_WAVES) {
+            const unsigned v = LC.cnt[i];
+            if (v) atomicAdd(&cnt[i], v);
+        }
+    }
 }
 
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
