@@ -301,9 +301,9 @@ class LpfContext:
         self._check(self._lib.lpf_set_cu_partition(self._h, int(side_cus), int(bool(exclusive))))
 
     def set_geometry(self, mode="auto"):
-        """Segment / tile sizes of a run: "auto" (by launch size), "small" (1024-point segments), "large" (4096) or
-        "large-scan" (4096, prefixes from the scan kernel); same results."""
-        self._check(self._lib.lpf_set_geometry(self._h, {"auto": 0, "small": 1, "large": 2, "large-scan": 3}[mode]))
+        """Segment / tile sizes of a run: "auto" (by launch size), "small" (1024-point segments, wide tail), "small-narrow",
+        "large" (4096) or "large-scan" (4096, prefixes from the scan kernel); same results."""
+        self._check(self._lib.lpf_set_geometry(self._h, {"auto": 0, "small": 1, "large": 2, "large-scan": 3, "small-narrow": 4}[mode]))
 
     def allreduce_metrics(self, vec, rccl_comm, op="sum"):
         """In-place all-reduce of an int64 NumPy vector over an RCCL communicator (an ncclComm_t as an integer /

@@ -586,7 +586,7 @@ int lpf_sync(lpf_ctx *c)
 int lpf_set_geometry(lpf_ctx *c, int mode)
 {
     if (!c) return LPF_ERR_ARG;
-    if (mode < 0 || mode > 3) return fail(c, LPF_ERR_ARG, "lpf_set_geometry: mode=%d (0 by launch size, 1 small, 2 large, 3 large with scan-kernel prefixes)", mode);
+    if (mode < 0 || mode > 4) return fail(c, LPF_ERR_ARG, "lpf_set_geometry: mode=%d (0 by launch size, 1 small with the wide tail, 2 large, 3 large with scan-kernel prefixes, 4 small with the narrow tail)", mode);
     c->geometry = mode;
     ++c->generation;
     return LPF_OK;
@@ -831,7 +831,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 
     // ---- segmentation: segments of 4096 points (1024 for small launches), one list wave each; K1 tiles subdivide them;
     //      groups of 64 segments are the second level of the counters ------------------------------------------------
-    const bool small = c->geometry == 1 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
+    const bool small = c->geometry == 1 || c->geometry == 4 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
     const int64_t seg_pts = small ? LPF_SEG_SMALL : LPF_SEG_QUANTUM;
     if (c->box_F && c->cand_dirty && (rc = launch_box_setup(c))) return rc;     // the camera changed since the boxes were set
     c->h_frames.resize(F);
@@ -1069,7 +1069,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
     }
     if (ntail > 0) {
-        if (small && count_boxes && nblk <= LPF_WIDE_BELOW) {   // a frame or a few, dense real segments: the box-count blocks share their chunks over 16 waves
+        if (small && count_boxes && c->geometry != 4 && (nblk <= LPF_WIDE_BELOW || c->geometry == 1)) {   // a frame or a few, dense real segments: the box-count blocks share their chunks over 16 waves
             if (pre_scan) hipLaunchKernelGGL((lpf_tail_wide_t<true>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
             else hipLaunchKernelGGL((lpf_tail_wide_t<false>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
         } else {

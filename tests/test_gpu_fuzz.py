@@ -55,7 +55,7 @@ def _case(seed, calib):
     return T, K, W, H, dmax, oriented, M, frames, masks, boxes
 
 
-@pytest.mark.parametrize("form", ["small", "large", "large-scan"])
+@pytest.mark.parametrize("form", ["small", "small-narrow", "large", "large-scan"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24"))))
 def test_fuzz_against_oracle(seed, form, calib):
     from lidar_object_detection_amd._native import LpfContext

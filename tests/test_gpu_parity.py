@@ -18,7 +18,7 @@ I32 = np.iinfo(np.int32)
 TOL = 1e-5
 
 
-@pytest.fixture(scope="module", params=["small", "large", "large-scan"])
+@pytest.fixture(scope="module", params=["small", "small-narrow", "large", "large-scan"])
 def ctx(request):
     """Every parity test runs under each launch geometry (lpf_set_geometry): 1024-point segments, 4096-point segments, and
     4096-point segments with the prefixes from the scan kernel (the path of frames beyond 16.7 M points)."""
