@@ -129,7 +129,7 @@ int  lpf_set_pipelined(lpf_ctx *ctx, int on);
 int  lpf_set_cu_partition(lpf_ctx *ctx, int side_cus, int exclusive);
 
 /* Launch geometry.  A run cuts every frame into segments -- one list wave each -- and K1 tiles: 1024-point segments of
- * 512-point tiles for launches of up to 4 Mi points (a real frame is then ~107 waves instead of 27), 4096-point
+ * 512-point tiles for launches of up to 3.5 Mi points (a real frame is then ~107 waves instead of 27), 4096-point
  * segments of 1024-point tiles beyond; a launch of a few frames runs the tail in its wide form (16 waves share the masked
  * points of four segments).  Results do not depend on any of it.  0 = by launch size (default), 1 = small with the wide
  * tail, 2 = large, 3 = large with the segment prefixes taken from the scan kernel (what frames of more than 64 x 64

@@ -16,8 +16,9 @@
 #include <vector>
 
 // Points per launch up to which a run uses the small geometry: 512-point K1 tiles and 1024-point segments (more,
-// shorter blocks and list waves: a single real frame is 107 segments instead of 27).
-#define LPF_SMALL_LAUNCH (4ll << 20)
+// shorter blocks and list waves: a single real frame is 107 segments instead of 27).  Measured on single synthetic clouds
+// (tools/geometry_probe.py, us per step small / large): 1 M 34.9 / 38.7, 2 M 38.5 / 46.9, 3 M 46.0 / 49.5, 4 M 57.1 / 52.0.
+#define LPF_SMALL_LAUNCH (7ll << 19)
 // Tail blocks (of four 1024-point segments) up to which the wide form of the tail runs (measured on copies of sample frame 100:
 // 1 frame = 27 blocks 22.5 vs 25.9 us; 6 frames 29.8 vs 32.8; 8 frames 34.4 vs 35.7; 20 frames = 535 blocks 55.4 vs 49.0 us)
 #define LPF_WIDE_BELOW 220
