@@ -104,7 +104,9 @@ def test_fuzz_software_pipelined_device_mode(seed, calib):
             o = dict(uv=torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev), label_bits=torch.empty(max(n, 1), dtype=torch.int32, device=dev),
                      valid_idx=torch.empty(max(n, 1), dtype=torch.int64, device=dev), inst_idx=torch.empty((F, cap), dtype=torch.int64, device=dev),
                      count_mb=torch.zeros(max(M * Btot, 1), dtype=torch.int32, device=dev),
-                     summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+                     summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+                     uv_valid=torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev),
+                     label_valid=torch.empty(max(n, 1), dtype=torch.int32, device=dev))
             mt = torch.from_numpy(np.stack(masks)).to(dev) if M else None
             torch.cuda.synchronize(dev)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
@@ -120,6 +122,7 @@ def test_fuzz_software_pipelined_device_mode(seed, calib):
         sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
         uv, lab = o["uv"].cpu().numpy(), o["label_bits"].cpu().numpy().view(np.uint32)
         vidx, iidx, cmb = o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy(), o["count_mb"].cpu().numpy()
+        uvv, labv = o["uv_valid"].cpu().numpy(), o["label_valid"].cpu().numpy().view(np.uint32)
         boff = 0
         for f in range(len(frames)):
             a, b = int(off[f]), int(off[f + 1])
@@ -128,6 +131,9 @@ def test_fuzz_software_pipelined_device_mode(seed, calib):
             assert np.array_equal(uv[a:b, 0], ref["u"]) and np.array_equal(uv[a:b, 1], ref["v"]), (seed, f)
             assert np.array_equal(lab[a:b], ref["label_bits"]), (seed, f)
             assert int(sm[f]["n_valid"]) == ref["n_valid"] and np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"]), (seed, f)
+            nv = ref["n_valid"]
+            assert np.array_equal(uvv[a:a + nv, 0], ref["u"][ref["valid_idx"]]) and np.array_equal(uvv[a:a + nv, 1], ref["v"][ref["valid_idx"]])
+            assert np.array_equal(labv[a:a + nv], ref["label_bits"][ref["valid_idx"]]), (seed, f)
             assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"]), (seed, f)
             for m in range(M):
                 lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
