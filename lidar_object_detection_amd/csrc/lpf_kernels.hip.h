@@ -816,21 +816,36 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
 // ------------------------------------------------------------------------------------
 #define LPF_SUMMARY_BYTES 928
 
-__device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const LpfFrame &fr, const int f, unsigned *s_tot)
+#define LPF_FIN_STAGE 1024        // inside counts staged in LDS (M x B up to this many: one memory round trip for everything)
+
+__device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const LpfFrame &fr, const int f, unsigned *s_tot, unsigned *s_c)
 {
     const int tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const int B = fr.B, M = P.M;
+    const int B = fr.B, M = P.M, MB = M * B;
     char *base = P.summary ? (char *)P.summary + (size_t)f * LPF_SUMMARY_BYTES : nullptr;
     long long *w = (long long *)base;
     int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
-    // the frame's totals: sum of the 8 shards K1's tiles added into (K1 is a finished kernel: plain loads)
+    unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
+    int32_t *out = P.count_out ? P.count_out + (size_t)M * fr.box_off : nullptr;
+    const bool staged = MB <= LPF_FIN_STAGE;
+    // ONE round trip: the frame's totals (sum of the 8 shards K1's tiles added into) and the inside counts are loaded
+    // together; the counts go to the caller and to LDS, their scratch is handed back zeroed
     const int ngroups = (2 + M + 3) >> 2;
-    if (tid < LPF_TAB_ROWS) {
-        unsigned a = 0;
-        if (tid < 4 * ngroups)
-            for (int sh = 0; sh < LPF_FRM_SHARDS; ++sh)
-                a += reinterpret_cast<const unsigned *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + sh) * LPF_TAB_GROUPS)[tid];
-        s_tot[tid] = (tid < 2 + M) ? a : 0u;
+    unsigned a = 0, cv[LPF_FIN_STAGE / LPF_BLOCK];
+    if (tid < 4 * ngroups)
+        for (int sh = 0; sh < LPF_FRM_SHARDS; ++sh)
+            a += reinterpret_cast<const unsigned *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + sh) * LPF_TAB_GROUPS)[tid];
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < LPF_FIN_STAGE / LPF_BLOCK; ++k) cv[k] = (tid + k * LPF_BLOCK < MB) ? cnt[tid + k * LPF_BLOCK] : 0u;
+    }
+    if (tid < LPF_TAB_ROWS) s_tot[tid] = (tid < 2 + M) ? a : 0u;
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < LPF_FIN_STAGE / LPF_BLOCK; ++k) {
+            const int i = tid + k * LPF_BLOCK;
+            if (i < MB) { s_c[i] = cv[k]; if (out) out[i] = (int32_t)cv[k]; cnt[i] = 0u; }
+        }
     }
     __syncthreads();
     const unsigned *__restrict__ tot = s_tot;
@@ -841,8 +856,7 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
         for (int i = tid; i < ngroups * ngrp; i += LPF_BLOCK) P.grp_tab[(size_t)(i / ngrp) * P.ngrp_cap + fr.grp_off + (i % ngrp)] = z;
         for (int i = tid; i < LPF_FRM_SHARDS * LPF_TAB_GROUPS; i += LPF_BLOCK) P.frm_tab[(size_t)f * LPF_FRM_SHARDS * LPF_TAB_GROUPS + i] = z;
     }
-    unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
-    auto cnt_at = [&](int i) { return cnt[i]; };
+    auto cnt_at = [&](int i) { return staged ? s_c[i] : cnt[i]; };
     // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     for (int m = wave; m < M; m += 4) {
         unsigned best = 0;
@@ -882,12 +896,12 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
             bb[33] = 0;
         }
     }
-    __syncthreads();
-    // hand the counters over and leave the scratch zeroed for the next call
-    int32_t *out = P.count_out ? P.count_out + (size_t)M * fr.box_off : nullptr;
-    for (int i = tid; i < M * B; i += LPF_BLOCK) {
-        if (out) out[i] = (int32_t)cnt_at(i);
-        cnt[i] = 0;
+    if (!staged) {                                          // many masks x many boxes: from memory, after every wave has read them
+        __syncthreads();
+        for (int i = tid; i < MB; i += LPF_BLOCK) {
+            if (out) out[i] = (int32_t)cnt[i];
+            cnt[i] = 0;
+        }
     }
 }
 
@@ -1031,10 +1045,10 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
 
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 {
-    __shared__ unsigned s_tot[LPF_TAB_ROWS];
+    __shared__ unsigned s_tot[LPF_TAB_ROWS], s_c[LPF_FIN_STAGE];
     const int f = blockIdx.x;
     const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
-    lpf_finalize_frame(P, fr, f, s_tot);
+    lpf_finalize_frame(P, fr, f, s_tot, s_c);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1065,7 +1079,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     if (b < Y.nfin8) {                                      // ---- summaries of run i-2
         if (b < Y.nfin) {
             const LpfFrame fr = (R.F > 1) ? R.frames[b] : R.frame0;
-            lpf_finalize_frame(R, fr, b, s_cnt);
+            lpf_finalize_frame(R, fr, b, s_cnt, reinterpret_cast<unsigned *>(s_raw));      // (16.7 KB of role LDS: room for the 4 KB stage)
         }
         return;
     }
