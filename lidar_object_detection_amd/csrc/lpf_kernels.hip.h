@@ -111,6 +111,27 @@ __device__ __forceinline__ int lpf_find_frame(const LpfFrame *frames, int F, int
     return lo;
 }
 
+// The frame record of a block: by value from the kernel arguments when the launch has one frame (no dependent load), else
+// from the table, and then made wave-uniform by hand.  Left to itself the compiler merges the two into one choice between
+// the two pointers, and the fields arrive through flat vector loads, one at each first use (and live in vector registers:
+// lpf_tail_t 70 -> 58 VGPRs with this).
+__device__ __forceinline__ int lpf_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long lpf_uni64(long long v)
+{
+    return (long long)(((unsigned long long)(unsigned)lpf_uni((int)((unsigned long long)v >> 32)) << 32) | (unsigned)lpf_uni((int)v));
+}
+__device__ __forceinline__ LpfFrame lpf_frame_record(const LpfFrame &by_value, const LpfFrame *table, const bool many, const int idx)
+{
+    LpfFrame fr = by_value;
+    if (many) {
+        const LpfFrame t = table[lpf_uni(idx)];
+        fr.pt_off = lpf_uni64(t.pt_off); fr.inst_base = lpf_uni64(t.inst_base); fr.N = lpf_uni(t.N); fr.seg_off = lpf_uni(t.seg_off);
+        fr.nseg = lpf_uni(t.nseg); fr.box_off = lpf_uni(t.box_off); fr.B = lpf_uni(t.B); fr.pad = lpf_uni(t.pad);
+        fr.cand_off = lpf_uni64(t.cand_off); fr.cand_words = lpf_uni(t.cand_words); fr.grp_off = lpf_uni(t.grp_off);
+    }
+    return fr;
+}
+
 // int32 pixel convention of the ABI: saturate, NaN -> INT32_MIN.  v_cvt_i32_f64 saturates
 // out-of-range inputs by itself (and gives 0 for NaN); r is already integral (rint).
 __device__ __forceinline__ int32_t lpf_sat_i32(double r)
@@ -452,7 +473,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_scan_segments(const LpfParams P
     __shared__ unsigned s_toff[LPF_TAB_GROUPS][LPF_BLOCK][4];
     __shared__ unsigned s_wsum[4][4], s_tot[LPF_TAB_ROWS], s_off[LPF_TAB_ROWS];
     const int f = blockIdx.x, tid = threadIdx.x, lane = lpf_lane(), wave = lpf_wave();
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     const int seg_lo = fr.seg_off, seg_hi = fr.seg_off + fr.nseg;
     const int ngroups = (2 + P.M + 3) >> 2;
     const int R = (fr.nseg + LPF_BLOCK - 1) / LPF_BLOCK;
@@ -722,11 +743,13 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
             const int e = (int)(ent & 63u), b = (int)(ent >> 6);
             const float4 x = s_pt[e];
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
-            bool in;
-            if (b < LPF_BC_LDSB) {
-                const double *bp = s_bp + b * 16;
+            int in;                                         // (LDS first, the rare box beyond it from memory afterwards: see below)
+            {
+                const double *bp = s_bp + (b & (LPF_BC_LDSB - 1)) * 16;
                 in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            } else {
+            }
+            asm volatile("" : "+v"(in));
+            if (b >= LPF_BC_LDSB) {
                 const double *bp = boxp + (size_t)b * 16;
                 in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
             }
@@ -774,9 +797,11 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
             mset &= mset - 1ull;
             bool near = false;
             if (has) {
-                float4 lo, hi;
-                if (b < 64) { lo = s_bq[2 * b]; hi = s_bq[2 * b + 1]; }
-                else { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
+                // (an LDS read, then a rare read from memory, kept apart by the empty asm: written as a choice between the two
+                //  pointers it compiles to flat loads -- and cost lpf_step_t two spilled registers)
+                float4 lo = s_bq[2 * (b & 63)], hi = s_bq[2 * (b & 63) + 1];
+                asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
+                if (b >= 64) { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
                 near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
             }
             const unsigned long long bal = __ballot(near);
@@ -856,7 +881,12 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
         for (int i = tid; i < ngroups * ngrp; i += LPF_BLOCK) P.grp_tab[(size_t)(i / ngrp) * P.ngrp_cap + fr.grp_off + (i % ngrp)] = z;
         for (int i = tid; i < LPF_FRM_SHARDS * LPF_TAB_GROUPS; i += LPF_BLOCK) P.frm_tab[(size_t)f * LPF_FRM_SHARDS * LPF_TAB_GROUPS + i] = z;
     }
-    auto cnt_at = [&](int i) { return staged ? s_c[i] : cnt[i]; };
+    auto cnt_at = [&](int i) {                              // (LDS, or memory for the rare big M x B; kept apart: see lpf_count_chunk)
+        unsigned v = s_c[i & (LPF_FIN_STAGE - 1)];
+        asm volatile("" : "+v"(v));
+        if (!staged) v = cnt[i];
+        return v;
+    };
     // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
     for (int m = wave; m < M; m += 4) {
         unsigned best = 0;
@@ -934,7 +964,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     const bool count_role = tb < ncount;
     const int2 ent = P.blks[count_role ? tb : tb - ncount]; // {first segment, frame << 3 | segments}
     const int f = ent.y >> 3, nw = ent.y & 7;
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
     } else {
@@ -962,10 +992,11 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     }
 }
 
-// 7 blocks per CU (72 VGPRs: no spills -- at 8 the kernel spills six registers per thread to scratch, which is HBM traffic too:
-// 111 vs 112 us per serial step); 61 SGPRs, 16.7 KB LDS
+// 8 blocks per CU: 58 VGPRs since the frame record lives in scalar registers (lpf_frame_record) and the LDS / memory choices are
+// kept apart (lpf_count_chunk); before that it needed 72, and forced to 64 it spilled six registers per thread to scratch
+// -- HBM traffic too.  16.7 KB LDS.
 template <bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     lpf_tail_block<PRE>(P, (int)blockIdx.x, s_raw);
@@ -1002,7 +1033,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     const bool count_role = tb < ncount;
     const int2 ent = P.blks[count_role ? tb : tb - ncount];
     const int f = ent.y >> 3, nw = ent.y & 7;
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
         return;
@@ -1047,7 +1078,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 {
     __shared__ unsigned s_tot[LPF_TAB_ROWS], s_c[LPF_FIN_STAGE];
     const int f = blockIdx.x;
-    const LpfFrame fr = (P.F > 1) ? P.frames[f] : P.frame0;
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     lpf_finalize_frame(P, fr, f, s_tot, s_c);
 }
 
@@ -1078,7 +1109,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     int b = (int)blockIdx.x;
     if (b < Y.nfin8) {                                      // ---- summaries of run i-2
         if (b < Y.nfin) {
-            const LpfFrame fr = (R.F > 1) ? R.frames[b] : R.frame0;
+            const LpfFrame fr = lpf_frame_record(R.frame0, R.frames, R.F > 1, b);
             lpf_finalize_frame(R, fr, b, s_cnt, reinterpret_cast<unsigned *>(s_raw));      // (16.7 KB of role LDS: room for the 4 KB stage)
         }
         return;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Duration of the list/box-count kernel on real-frame-shaped input, by HIP events around whole steps with the
 kernel form forced: frame 100 of the sample (109 355 points, 5 masks, 25 boxes), F copies batched.
-usage: python tools/k2_probe.py [F]"""
+usage: python tools/k2_probe.py [F] [full|nolists|noboxes|bare|validonly|instonly]   (drop the lists, the boxes or both: what each phase costs)"""
 import os
 import sys
 import time
@@ -18,6 +18,7 @@ def main():
     from conftest import load_calib, load_golden, unpack_masks
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    variant = sys.argv[2] if len(sys.argv) > 2 else "full"
     calib = load_calib(); g = load_golden(100)
     W, H = int(calib["width"]), int(calib["height"])
     T, K3 = np.asarray(calib["TrVeloToRect"]), np.asarray(calib["K"])[:3, :3]
@@ -33,25 +34,32 @@ def main():
                  valid_idx=torch.empty(F * n, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, n), dtype=torch.int64, device=dev),
                  count_mb=torch.zeros(F * M * B, dtype=torch.int32, device=dev),
                  summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        if variant in ("nolists", "bare"):
+            o.pop("valid_idx"); o.pop("inst_idx")
+        if variant == "validonly":
+            o.pop("inst_idx")
+        if variant == "instonly":
+            o.pop("valid_idx")
         for form in ("small", "large"):
             ctx = LpfContext(0)
             ctx.set_stream(stream.cuda_stream)
             ctx.set_camera(T, K3, W, H, 0.0, 50.0)
-            ctx.set_boxes([corners] * F)
+            if variant not in ("noboxes", "bare", "validonly", "instonly"):
+                ctx.set_boxes([corners] * F)
             ctx.set_geometry(form)
             step = ctx.make_device_step(d_pts, off, masks_u8=d_masks, erode_iters=0, inst_cap=n, **o)
             for _ in range(20):
                 step()
             stream.synchronize()
             cm = o["count_mb"].cpu().numpy().reshape(F, M, B)
-            assert all(np.array_equal(cm[f], g["count_mb_rect5_d50"]) for f in range(F))
+            assert variant in ("noboxes", "bare", "validonly", "instonly") or all(np.array_equal(cm[f], g["count_mb_rect5_d50"]) for f in range(F))
             t0 = time.perf_counter()
             for _ in range(500):
                 step()
             stream.synchronize()
             res[form] = (time.perf_counter() - t0) / 500 * 1e6
             ctx.close()
-    print("F=%d frames of %d points: %s" % (F, n, "  ".join("%s %.1f us/step" % kv for kv in res.items())))
+    print("%-8s F=%d frames of %d points: %s" % (variant, F, n, "  ".join("%s %.1f us/step" % kv for kv in res.items())))
 
 
 if __name__ == "__main__":
