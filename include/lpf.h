@@ -152,7 +152,13 @@ int lpf_set_camera(lpf_ctx *ctx, const double T_velo_to_rect[16], const double K
  *   binarize = 2 : member <=> mask > 0.5 on the raw float mask   (Same_color.py:125, vis.py:185,
  *                  seg_with_pointcloud.py:167: the scripts that index the YOLO mask without astype)
  * erode_iters: iterations of cv2.erode with the 3x3 MORPH_ELLIPSE (cross) element (V3:83-90).
- * The packed result is a uint32 label image [F][H][W], bit m = mask m, kept in HBM. */
+ * The packed result is a label image [F][H][W], bit m = mask m, kept in HBM.
+ * on_device: 0 = host memory (copied before the call returns); 1 = device memory, packed in stream order by this call (the
+ *   buffer may be rewritten, in stream order, as soon as the call has returned); 2 = device memory LENT to the context: it
+ *   stays unchanged until every run that uses these masks has completed.  Lent masks (and host masks, which sit in the
+ *   context's own staging buffer) that need no erosion are not packed at the call in serial mode: a small launch (a real
+ *   frame or a few) then looks a valid point's M mask values up directly -- ~20 k points x M bytes instead of a separate
+ *   4.7 us launch over 530 k pixels x M -- and a large one packs them first, on the same stream.  Same results. */
 int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode_iters, int on_device);
 int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int binarize,
                       int erode_iters, int on_device);

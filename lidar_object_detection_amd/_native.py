@@ -354,11 +354,14 @@ class LpfContext:
 
     BINARIZE = {"astype": 0, "v3": 1, "gt0.5": 2}
 
-    def set_masks(self, masks, erode_iters=0, v3_pipeline=False, binarize=None):
+    def set_masks(self, masks, erode_iters=0, v3_pipeline=False, binarize=None, lend=False):
         """masks: [M,H,W] or [F,M,H,W]; uint8/bool (nonzero = member) or float32 (reference masks).
         NumPy array, or torch tensor already on the GPU.  Float masks: ``binarize`` is "astype"
         (mask.astype(uint8) != 0, V3:222-225), "v3" (the V3:82-97 erosion block's casts; same as
-        v3_pipeline=True) or "gt0.5" (mask > 0.5, Same_color.py:125 / vis.py:185)."""
+        v3_pipeline=True) or "gt0.5" (mask > 0.5, Same_color.py:125 / vis.py:185).
+        lend=True (GPU tensors): the tensor stays untouched until the runs that use these masks have completed, so a
+        small launch may read it directly instead of packing it first (on_device = 2 of the C ABI); the context keeps
+        a reference to it until the masks are replaced."""
         if binarize is None:
             binarize = "v3" if v3_pipeline else "astype"
         if binarize not in self.BINARIZE:
@@ -382,10 +385,12 @@ class LpfContext:
             a = np.ascontiguousarray(a, dtype=np.float32 if is_f else np.uint8)
             ptr = a.ctypes.data if M else None
             keep = a
+        where = (2 if lend else 1) if dev else 0
         if is_f:
-            rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, self.BINARIZE[binarize], int(erode_iters), int(dev))
+            rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, self.BINARIZE[binarize], int(erode_iters), where)
         else:
-            rc = self._lib.lpf_set_masks_u8(self._h, ptr, F, M, int(erode_iters), int(dev))
+            rc = self._lib.lpf_set_masks_u8(self._h, ptr, F, M, int(erode_iters), where)
+        self._lent_masks = keep if (dev and lend) else None
         del keep
         self._check(rc)
         self.F_masks, self.M = F, M
@@ -626,7 +631,7 @@ class LpfContext:
             self.F_masks, self.M = F, M
 
             def fn(_keep=(off, o, pts, masks_u8, outs)):
-                rc = setm(h, p_m, F, M, it, 1)
+                rc = setm(h, p_m, F, M, it, 2)               # lent: the closure holds the tensor, and the run follows at once
                 if rc == 0:
                     rc = run(h, p_pts, p_off, F, 1, p_out)
                 if rc:

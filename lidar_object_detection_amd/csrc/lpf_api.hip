@@ -59,6 +59,9 @@ struct lpf_ctx {
     // masks -> label images
     int mask_F = 0, mask_M = 0;       // 0 frames = no masks set
     DevBuf mask_stage;
+    // Masks not packed yet (serial mode, no erosion, host masks in mask_stage or device masks the caller lends: on_device 2):
+    // a small launch reads them directly in K1 (LpfDirect), anything else packs them first (ensure_packed).
+    struct Lazy { bool valid = false; const void *p = nullptr; bool f32 = false; int mode = 0; } lazy;
 
     // boxes
     int box_F = 0, oriented = 1;
@@ -432,7 +435,7 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
                                                       c->sc[1].mask_pending) && (rc = sync_all(c))) return rc;
     lpf_ctx::Scratch &S = c->sc[per_set ? c->parity : 0];
     hipStream_t ms = pipe ? c->stream_c : c->stream;
-    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr;
+    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
     if (F == 0) return LPF_OK;
     const size_t hw = (size_t)c->H * c->W;
     if ((rc = reserve(c, S.label_a, (size_t)F * hw * 4))) return rc;
@@ -447,6 +450,15 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         d_masks = (const T *)c->mask_stage.p;
     }
     const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
+    if (M > 0 && erode_iters == 0 && !c->pipelined && on_device != 1) {
+        // serial mode, nothing to erode, and the masks stay where they are (our staging buffer, or lent by the caller):
+        // packing is left to the run -- a small launch does without it
+        c->lazy.valid = true; c->lazy.p = d_masks; c->lazy.f32 = sizeof(T) == 4; c->lazy.mode = mode;
+        S.label_bytes = lb;
+        if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));
+        c->mask_F = F; c->mask_M = M;
+        return LPF_OK;
+    }
     void *cur = nullptr;
     if (lb == 1) rc = pack_typed<T, uint8_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
     else if (lb == 2) rc = pack_typed<T, uint16_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
@@ -457,6 +469,31 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (pipe) { LPF_HIP(c, hipEventRecord(S.mask_done, ms)); S.mask_pending = true; }
     S.label_cur = cur;
     c->mask_F = F; c->mask_M = M;
+    return LPF_OK;
+}
+
+// masks left unpacked by lpf_set_masks_* -> label image of scratch set 0, on the main stream
+int ensure_packed(lpf_ctx *c)
+{
+    if (!c->lazy.valid) return LPF_OK;
+    lpf_ctx::Scratch &S = c->sc[0];
+    const int F = c->mask_F, M = c->mask_M, lb = S.label_bytes;
+    void *cur = nullptr;
+    int rc;
+    if (c->lazy.f32) {
+        const float *m = (const float *)c->lazy.p;
+        if (lb == 1) rc = pack_typed<float, uint8_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+        else if (lb == 2) rc = pack_typed<float, uint16_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+        else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+    } else {
+        const uint8_t *m = (const uint8_t *)c->lazy.p;
+        if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+        else if (lb == 2) rc = pack_typed<uint8_t, uint16_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+        else rc = pack_typed<uint8_t, uint32_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
+    }
+    if (rc) return rc;
+    S.label_cur = cur;
+    c->lazy.valid = false;
     return LPF_OK;
 }
 
@@ -630,6 +667,7 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
                                                       "3 = 1 + mask packing on a side stream)", on);
     int rc = sync_all(c);
     if (rc) return rc;
+    if ((rc = ensure_packed(c))) return rc;
     const bool streams = on == 1 || on == 3;
     if (streams && !c->stream_b && (rc = make_side_streams(c))) return rc;
     for (auto &S : c->sc) {
@@ -677,7 +715,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
         int rc_ = sync_all(c);
         if (rc_) return rc_;
     }
-    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->box_F = 0; c->box_off.clear(); }   // label images and the
+    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->lazy.valid = false; c->box_F = 0; c->box_off.clear(); }   // label images and the
                                                                        // candidate grid are per W x H: set masks / boxes again
     memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
     memcpy(c->K, K, sizeof c->K);
@@ -708,7 +746,7 @@ int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_
     int rc;
     if ((rc = sync_all(c))) return rc;
     lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
-    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr;
+    c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
     if (F == 0) return LPF_OK;
     const size_t bytes = (size_t)F * c->H * c->W * 4;
     if ((rc = reserve(c, S.label_a, bytes))) return rc;
@@ -725,6 +763,7 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
     if (!c || !out) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     { int rc_ = sync_all(c); if (rc_) return rc_; }
+    { int rc_ = ensure_packed(c); if (rc_) return rc_; }
     lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
     if (!S.label_cur || !c->mask_F) return fail(c, LPF_ERR_STATE, "no masks set");
     const size_t npix = (size_t)c->mask_F * c->H * c->W;
@@ -900,7 +939,10 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap; P.ngrp_cap = ngrp_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
-    P.label_img = (M > 0) ? S.label_cur : nullptr;
+    // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
+    const bool direct = M > 0 && c->lazy.valid && small && !pipe_any;
+    if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
+    P.label_img = (M > 0) ? (direct ? c->lazy.p : S.label_cur) : nullptr;
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
@@ -1053,7 +1095,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (nk1 > 0) {
         const dim3 g1((unsigned)nk1);
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
-        if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
+        if (direct) {
+            typedef LpfDirect<uint8_t, 0> D0; typedef LpfDirect<float, 1> D1; typedef LpfDirect<float, 2> D2; typedef LpfDirect<float, 3> D3;
+            if (!c->lazy.f32) LPF_K1_LAUNCH(2, D0);
+            else if (c->lazy.mode == 1) LPF_K1_LAUNCH(2, D1);
+            else if (c->lazy.mode == 2) LPF_K1_LAUNCH(2, D2);
+            else LPF_K1_LAUNCH(2, D3);
+        } else if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
         else       { if (lb == 1) LPF_K1_LAUNCH(4, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(4, uint16_t); else LPF_K1_LAUNCH(4, uint32_t); }
 #undef LPF_K1_LAUNCH
         LPF_HIP(c, hipGetLastError());

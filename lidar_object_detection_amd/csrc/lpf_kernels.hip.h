@@ -199,6 +199,56 @@ __device__ __forceinline__ void lpf_project_point_mem(const double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// Mask membership rules (V3:222-235 / cvs_erosion.py: what the reference's binarisation makes of a mask value) and the two
+// sources K1 takes a point's label bits from: the packed label image (one gather per point), or -- small launches whose
+// masks need no erosion -- the caller's masks themselves, M gathers per VALID point issued together.  A real frame has
+// ~20 k valid points against 530 k pixels x M masks: packing first costs a 4.7 us launch that reads 2.6 MB to serve them.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lpf_f32_to_u8(float v)
+{
+    int t;
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) t = INT32_MIN; else t = (int)v;
+    return (unsigned)t & 0xFFu;
+}
+
+template <typename T, int MODE>
+__device__ __forceinline__ bool lpf_member(T v)
+{
+    if (MODE == 0) return v != 0;
+    if (MODE == 1) return lpf_f32_to_u8((float)v) != 0u;
+    if (MODE == 3) return (float)v > 0.5f;
+    return lpf_f32_to_u8((float)v * 255.0f) == 255u;
+}
+
+template <typename T, int MODE> struct LpfDirect { };        // tag: label bits straight from masks of element T under rule MODE
+
+template <typename LT>
+struct LpfLabelSrc {                                         // packed label image [F][H][W] of LT
+    typedef LT elem;
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ img, const LpfParams &, const int pix) { return (uint32_t)img[pix]; }
+    static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.W * (size_t)P.H; }
+};
+template <typename T, int MODE>
+struct LpfLabelSrc<LpfDirect<T, MODE> > {                    // masks [F][M][H][W] of T
+    typedef T elem;
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ msk, const LpfParams &P, const int pix)
+    {
+        const size_t hw = (size_t)P.W * (size_t)P.H;
+        uint32_t l = 0;
+        for (int m0 = 0; m0 < P.M; m0 += 8) {                // eight loads in flight, then their tests (M <= 8: one round trip)
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = msk[(size_t)min(m0 + j, P.M - 1) * hw + pix];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (m0 + j < P.M && lpf_member<T, MODE>(v[j])) l |= 1u << (m0 + j);
+        }
+        return l;
+    }
+    static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.M * (size_t)P.W * (size_t)P.H; }
+};
+
+// ------------------------------------------------------------------------------------
 // K1: one block = one tile of 256*ROWS consecutive points of one frame (a segment of 4096 points is 4 or 8
 // tiles); a wave owns ROWS consecutive rows of 64 points.  All float4 loads of a lane are issued before the
 // first use, the label gathers are issued as soon as a row's pixel is known, and only then do the ballots /
@@ -234,8 +284,9 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
     const int c = seg_start + (lb - sid * tiles_per_seg) * TILE;       // first point of the tile
     if (c >= seg_end) return;                                            // padding tile of a short segment
     const float4 *__restrict__ pts = P.pts + fr.pt_off;
-    const LT *__restrict__ limg =
-        (P.label_img && P.M > 0) ? static_cast<const LT *>(P.label_img) + (size_t)f * (size_t)P.W * (size_t)P.H : nullptr;
+    typedef LpfLabelSrc<LT> Src;
+    const typename Src::elem *__restrict__ limg =
+        (P.label_img && P.M > 0) ? static_cast<const typename Src::elem *>(P.label_img) + (size_t)f * Src::frame_stride(P) : nullptr;
     const int rows_per_seg = P.seg_pts >> 6;
     if (tid < LPF_TAB_ROWS) s_cnt[tid] = 0;
     __syncthreads();
@@ -281,7 +332,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
             // K4: label gather (2.1 MB image, L2 resident); consumed after the loop
             lab[r] = 0;
             if (!(FL & LPF_F_LAB_NOGATHER)) {
-                if (ok && limg) lab[r] = (uint32_t)limg[vi * P.W + ui];
+                if (ok && limg) lab[r] = Src::get(limg, P, vi * P.W + ui);
             }
             if (live && !(FL & LPF_F_LAB_NOSTORE)) {
                 const long long g = fr.pt_off + idx;
@@ -349,7 +400,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
     }
 }
 
-template <int ROWS, unsigned FL, typename LT = uint32_t>   // LT: label-image element (uint8 for M <= 8, uint16 for M <= 16)
+template <int ROWS, unsigned FL, typename LT = uint32_t>   // LT: label-image element (uint8 for M <= 8, uint16 for M <= 16), or LpfDirect<T, MODE>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_k1_project_t(const LpfParams P)
 {
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
@@ -1408,22 +1459,6 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_setup_kernel(const LpfBoxSe
 //   MODE 0: uint8, nonzero.  MODE 1: float, astype(uint8) != 0.  MODE 2: float, (x*255) -> u8 == 255.
 //   MODE 3: float, x > 0.5 (NaN is not a member).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned lpf_f32_to_u8(float v)
-{
-    int t;
-    if (!(v > -2147483904.0f && v < 2147483648.0f)) t = INT32_MIN; else t = (int)v;
-    return (unsigned)t & 0xFFu;
-}
-
-template <typename T, int MODE>
-__device__ __forceinline__ bool lpf_member(T v)
-{
-    if (MODE == 0) return v != 0;
-    if (MODE == 1) return lpf_f32_to_u8((float)v) != 0u;
-    if (MODE == 3) return (float)v > 0.5f;
-    return lpf_f32_to_u8((float)v * 255.0f) == 255u;
-}
-
 // Streaming pack, 16 pixels per lane: uint8 masks are read 16 bytes per lane per mask
 // (float masks 4 x 16 bytes), the packed labels leave as four 16-byte stores.
 // Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).

@@ -727,7 +727,7 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         corners.append(c)
         positions.append(pos)
     ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
-    ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline)
+    ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline, lend=True)   # (the run follows in this call: GPU masks can be lent)
     ctx.set_boxes(corners, oriented=use_oriented)
     # only the valid points' pixels and labels are used below: fetch those (a quarter of the dense arrays on real frames)
     res = ctx.run_batch([f.points for f in frames], want_uv=False, want_label=False, want_valid_uv=True)
