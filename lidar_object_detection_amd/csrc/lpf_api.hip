@@ -152,6 +152,12 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 // software-pipelined mode: launch what earlier runs still owe, on the context's stream
+void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
+{
+    if (pre) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
+    else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
+}
+
 int flush_pending(lpf_ctx *c)
 {
     if (c->pend_fin.valid) {
@@ -162,8 +168,7 @@ int flush_pending(lpf_ctx *c)
     if (c->pend_tail.valid) {
         const lpf_ctx::Pending &T = c->pend_tail;
         if (T.ntail > 0) {
-            if (T.pre) hipLaunchKernelGGL((lpf_tail_t<true>), dim3(T.ntail), dim3(LPF_BLOCK), 0, c->stream, T.P);
-            else hipLaunchKernelGGL((lpf_tail_t<false>), dim3(T.ntail), dim3(LPF_BLOCK), 0, c->stream, T.P);
+            launch_tail(c->stream, T.P, T.ntail, T.pre);
             LPF_HIP(c, hipGetLastError());
         }
         hipLaunchKernelGGL(lpf_finalize, dim3(T.P.F), dim3(LPF_BLOCK), 0, c->stream, T.P);
@@ -1122,8 +1127,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             if (pre_scan) hipLaunchKernelGGL((lpf_tail_wide_t<true>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
             else hipLaunchKernelGGL((lpf_tail_wide_t<false>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
         } else {
-            if (pre_scan) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
-            else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, tail_stream, P);
+            launch_tail(tail_stream, P, ntail, pre_scan);
         }
         LPF_HIP(c, hipGetLastError());
     }

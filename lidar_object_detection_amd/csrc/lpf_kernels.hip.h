@@ -593,20 +593,19 @@ __device__ __forceinline__ void lpf_bits_to_list(unsigned long long rowbits, uns
     }
 }
 
-template <bool PRE>
-__device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned short *lst)
+// lane c: entries of counter c (0 valid, 1 masked, 2+m instance m) in the frame before segment sid (bef) and in the whole frame
+// (tot; PRE: bef of the instance counters already includes inst_off[m], tot is not produced).  Without the scan kernel the
+// wave sums its group's segments and the frame's groups, a lane each.  STEP = 2 (one round trip up to six masks) is what the
+// software-pipelined step kernel uses (98.1 vs 98.6 us per step); in the stand-alone tail kernels the same code measured
+// worse on small launches (45.2 vs 41.3 us for a batch of 20 real frames, even when only present, not executed), so they
+// take the groups one at a time.
+template <bool PRE, int STEP>               // STEP: counter groups whose loads are in flight together (1 or 2)
+__device__ __forceinline__ void lpf_list_prefix(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned &bef, unsigned &tot)
 {
     const int lane = lpf_lane();
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const int ngroups = (2 + P.M + 3) >> 2;
-    const int rps = P.seg_pts >> 6;                        // ballot rows per segment: 16 or 64
-    const int k = sid - fr.seg_off;                        // segment of its frame
-    unsigned long long vb = 0, mb = 0;
-    if (lane < rps) {
-        vb = P.vbal[(size_t)sid * rps + lane];
-        mb = P.mbal[(size_t)sid * rps + lane];
-    }
-    unsigned bef = 0, tot = 0;                             // lane c: entries of counter c before this segment / in the frame
+    const int k = sid - fr.seg_off;
+    bef = 0; tot = 0;
     if (PRE) {
         uint4 q = make_uint4(0u, 0u, 0u, 0u);
         if (lane < ngroups) q = P.seg_pre[(size_t)lane * P.nseg_cap + sid];
@@ -615,19 +614,63 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
         bef = ((lane & 3) == 0) ? x : ((lane & 3) == 1) ? y : ((lane & 3) == 2) ? z : w;   // instance counters: inst_off[m] included
     } else {
         const int gi = k >> 6, j = k & 63;                 // group of 64 segments, place in it (gi < 64: host guarantees)
-        for (int g = 0; g < ngroups; ++g) {
-            uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, t = a;
-            if (lane < j) a = P.seg_tab[(size_t)g * P.nseg_cap + fr.seg_off + (gi << 6) + lane];
-            if (lane < gi) b = P.grp_tab[(size_t)g * P.ngrp_cap + fr.grp_off + lane];
-            if (lane < LPF_FRM_SHARDS) t = P.frm_tab[((size_t)fr.pad * LPF_FRM_SHARDS + lane) * LPF_TAB_GROUPS + g];
-            const unsigned px = lpf_wave_sum(a.x + b.x), py = lpf_wave_sum(a.y + b.y), pz = lpf_wave_sum(a.z + b.z), pw = lpf_wave_sum(a.w + b.w);
-            const unsigned tx = lpf_sum8(t.x), ty = lpf_sum8(t.y), tz = lpf_sum8(t.z), tw = lpf_sum8(t.w);
-            if ((lane >> 2) == g) {
-                bef = ((lane & 3) == 0) ? px : ((lane & 3) == 1) ? py : ((lane & 3) == 2) ? pz : pw;
-                tot = ((lane & 3) == 0) ? tx : ((lane & 3) == 1) ? ty : ((lane & 3) == 2) ? tz : tw;
+        for (int g0 = 0; g0 < ngroups; g0 += STEP) {
+            uint4 a[STEP], b[STEP], t[STEP];
+#pragma unroll
+            for (int u = 0; u < STEP; ++u) {
+                const int g = g0 + u;
+                a[u] = make_uint4(0u, 0u, 0u, 0u); b[u] = a[u]; t[u] = a[u];
+                if (g < ngroups) {
+                    if (lane < j) a[u] = P.seg_tab[(size_t)g * P.nseg_cap + fr.seg_off + (gi << 6) + lane];
+                    if (lane < gi) b[u] = P.grp_tab[(size_t)g * P.ngrp_cap + fr.grp_off + lane];
+                    if (lane < LPF_FRM_SHARDS) t[u] = P.frm_tab[((size_t)fr.pad * LPF_FRM_SHARDS + lane) * LPF_TAB_GROUPS + g];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < STEP; ++u) {
+                const int g = g0 + u;
+                if (g >= ngroups) break;
+                const unsigned px = lpf_wave_sum(a[u].x + b[u].x), py = lpf_wave_sum(a[u].y + b[u].y), pz = lpf_wave_sum(a[u].z + b[u].z), pw = lpf_wave_sum(a[u].w + b[u].w);
+                const unsigned tx = lpf_sum8(t[u].x), ty = lpf_sum8(t[u].y), tz = lpf_sum8(t[u].z), tw = lpf_sum8(t[u].w);
+                if ((lane >> 2) == g) {
+                    bef = ((lane & 3) == 0) ? px : ((lane & 3) == 1) ? py : ((lane & 3) == 2) ? pz : pw;
+                    tot = ((lane & 3) == 0) ? tx : ((lane & 3) == 1) ? ty : ((lane & 3) == 2) ? tz : tw;
+                }
             }
         }
     }
+}
+
+// lane m: where the next entry of mask m goes in the frame's concatenated instance lists
+template <bool PRE>
+__device__ __forceinline__ unsigned lpf_list_posreg(const LpfParams &P, const unsigned bef, const unsigned tot)
+{
+    const int lane = lpf_lane();
+    if (PRE) return (unsigned)__shfl((int)bef, (lane + 2) & 63);
+    unsigned off = (lane >= 2 && lane < 2 + P.M) ? tot : 0u;      // inst_off[m] = totals of the masks before m
+    const unsigned own = off;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(off, o);
+        if (lane >= o) off += u;
+    }
+    return (unsigned)__shfl((int)(off - own + bef), (lane + 2) & 63);
+}
+
+template <bool PRE, int STEP>
+__device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned short *lst)
+{
+    const int lane = lpf_lane();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int rps = P.seg_pts >> 6;                        // ballot rows per segment: 16 or 64
+    const int k = sid - fr.seg_off;                        // segment of its frame
+    unsigned long long vb = 0, mb = 0;
+    if (lane < rps) {
+        vb = P.vbal[(size_t)sid * rps + lane];
+        mb = P.mbal[(size_t)sid * rps + lane];
+    }
+    unsigned bef, tot;
+    lpf_list_prefix<PRE, STEP>(P, fr, sid, bef, tot);
     const int seg_start = k * P.seg_pts;
     const int seg_end = min(seg_start + P.seg_pts, fr.N);
     const int nrows = (seg_end - seg_start + 63) >> 6;
@@ -674,20 +717,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
     }
     if (L == 0 || P.inst_idx == nullptr) return;
 
-    // lane m: where the next entry of mask m goes in the frame's concatenated lists
-    unsigned posreg;
-    if (PRE) {
-        posreg = (unsigned)__shfl((int)bef, (lane + 2) & 63);
-    } else {
-        unsigned off = (lane >= 2 && lane < 2 + P.M) ? tot : 0u;      // inst_off[m] = totals of the masks before m
-        const unsigned own = off;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(off, o);
-            if (lane >= o) off += u;
-        }
-        posreg = (unsigned)__shfl((int)(off - own + bef), (lane + 2) & 63);
-    }
+    unsigned posreg = lpf_list_posreg<PRE>(P, bef, tot);
     // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
     // the same order as the set bits of the masked ballots: entry e of the segment, found in
     // row r, is entry e - mbase[first row of r's K1 wave] of that wave.
@@ -710,16 +740,28 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
                 lpf_bits_to_list(mb, mbase - start, lane, lst);
             }
             __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: reads below see the writes
-            for (unsigned e0 = 0; e0 < cnt; e0 += 64) {
-                const unsigned e = e0 + lane;
-                const bool act = e < cnt;
-                const unsigned li = lst[act ? e : 0];      // segment-relative point index
-                const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
-                const unsigned wb = (unsigned)__shfl((int)mbase, first_row);            // all lanes take part
-                unsigned lab = 0u;                         // only the label bits of the hand-off entry are needed here
-                if (act) lab = __float_as_uint(mseg[first_row * 64 + (int)(start + e - wb)].w);
-                {                                          // split by instance; ballot order == ascending point index
-                    const long long idx = (long long)(seg_start + (int)li);
+            // four chunks of 64 entries at a time: their label reads (one dependent round trip each) are issued together,
+            // then split one after the other -- chunk by chunk, a segment lying on a car (hundreds of masked points) cost
+            // the wave a memory latency per chunk, the longest chain of a small launch's tail (8.4 us measured)
+            for (unsigned e0 = 0; e0 < cnt; e0 += 256) {
+                unsigned lab4[4], li4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lab4[q] = 0u; li4[q] = 0u;
+                    if (e0 + 64u * q >= cnt) continue;     // (wave-uniform: most segments of a sparse launch hold one chunk)
+                    const unsigned e = e0 + 64u * q + lane;
+                    const bool act = e < cnt;
+                    const unsigned li = lst[act ? e : 0];  // segment-relative point index
+                    const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
+                    const unsigned wb = (unsigned)__shfl((int)mbase, first_row);        // all lanes take part
+                    li4[q] = li;                           // (only the label bits of the hand-off entry are needed here)
+                    if (act) lab4[q] = __float_as_uint(mseg[first_row * 64 + (int)(start + e - wb)].w);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {              // split by instance; ballot order == ascending point index
+                    if (e0 + 64u * q >= cnt) continue;
+                    const unsigned lab = lab4[q];
+                    const long long idx = (long long)(seg_start + (int)li4[q]);
                     unsigned any = lpf_wave_or(lab);
                     while (any) {
                         const int m = __ffs(any) - 1;
@@ -738,6 +780,94 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
             __builtin_amdgcn_wave_barrier();               // the list is rewritten by the next pass
         }
         r0 = r1;
+    }
+}
+
+// The same for a segment of a SMALL launch (16 rows of 64 points), where nothing but latency counts: no LDS list, no
+// chunks -- the rows are walked one after the other with lane = point.  The label of every masked point is read from the
+// hand-off slots as soon as the ballots are in (its slot follows from the row prefixes alone), so those reads and the
+// counter reads are one round trip; then valid_idx row by row, then each row with masked points is split by instance
+// (rows ascending, lanes ascending = point order).  A frame's slowest list wave: 8.4 -> 4.6 us.
+template <bool PRE>
+__device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const LpfFrame &fr, const int sid)
+{
+    constexpr int RPS = LPF_SEG_SMALL >> 6;
+    const int lane = lpf_lane();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int k = sid - fr.seg_off;
+    unsigned long long vb = 0, mb = 0;
+    if (lane < RPS) {
+        vb = P.vbal[(size_t)sid * RPS + lane];
+        mb = P.mbal[(size_t)sid * RPS + lane];
+    }
+    const int seg_start = k * LPF_SEG_SMALL;
+    const int seg_end = min(seg_start + LPF_SEG_SMALL, fr.N);
+    const int nrows = (seg_end - seg_start + 63) >> 6;
+    if (lane >= nrows) { vb = 0; mb = 0; }                 // rows K1 never wrote
+    const unsigned cv = __popcll(vb), cm = __popcll(mb);
+    unsigned iv = cv, im = cm;
+#pragma unroll
+    for (int o = 1; o < RPS; o <<= 1) {                    // inclusive scan over the row counts (lanes >= 16 hold zeros)
+        const unsigned tv = __shfl_up(iv, o), tm = __shfl_up(im, o);
+        if (lane >= o) { iv += tv; im += tm; }
+    }
+    const unsigned vbase = iv - cv, mbase = im - cm;
+    const unsigned nv = lpf_rl(iv, RPS - 1), L = lpf_rl(im, RPS - 1);
+    const bool want_inst = L != 0 && P.inst_idx != nullptr;
+    unsigned labr[RPS];
+    if (want_inst) {
+        // K1 left each of its waves' masked points compacted at the wave's first slot, in ballot order: the masked point of
+        // (row r, lane l) is entry mbase[r] + popc(bits below l) of the segment, entry - mbase[first row of r's K1 wave] of that wave
+        const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+        const int rows_per_wave = P.tile_pts >> 8;
+        const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
+#pragma unroll
+        for (int r = 0; r < RPS; ++r) {
+            const unsigned long long rm = lpf_rl64(mb, r);                              // wave-uniform
+            labr[r] = 0u;
+            if (rm) {
+                const int first_row = (r >> rpw_shift) << rpw_shift;
+                const unsigned at = lpf_rl(mbase, r) - lpf_rl(mbase, first_row) + __popcll(rm & lt);
+                if ((rm >> lane) & 1ull) labr[r] = __float_as_uint(mseg[first_row * 64 + (int)at].w);
+            }
+        }
+    }
+    unsigned bef, tot;
+    lpf_list_prefix<PRE, 1>(P, fr, sid, bef, tot);
+    const long long run_v = (long long)lpf_rl(bef, 0);     // valid points of the frame before this segment
+    if (P.valid_idx && nv) {
+        long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
+        const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        for (int r = 0; r < nrows; ++r) {
+            const unsigned long long rv = lpf_rl64(vb, r);                              // wave-uniform
+            if (rv == 0ull) continue;
+            if ((rv >> lane) & 1ull) {
+                const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+                dst[pos] = (long long)(seg_start + r * 64 + lane);
+                if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
+                if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
+            }
+        }
+    }
+    if (!want_inst) return;
+    unsigned posreg = lpf_list_posreg<PRE>(P, bef, tot);
+#pragma unroll
+    for (int r = 0; r < RPS; ++r) {
+        const unsigned lab = labr[r];
+        unsigned any = lpf_wave_or(lab);
+        const long long idx = (long long)(seg_start + r * 64 + lane);
+        while (any) {
+            const int m = __ffs(any) - 1;
+            any &= any - 1u;
+            const bool hit = (lab >> m) & 1u;
+            const unsigned long long bal = __ballot(hit);
+            const long long base = (long long)lpf_rl(posreg, m);
+            if (hit) {
+                const long long w = base + __popcll(bal & lt);
+                if (w < P.inst_cap) P.inst_idx[fr.inst_base + w] = idx;
+            }
+            if (lane == m) posreg += (unsigned)__popcll(bal);
+        }
     }
 }
 
@@ -1005,7 +1135,7 @@ struct LpfTailCountLds {
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
 
 // one tail block: the first nblk count boxes (when there are any: the longer chain goes first), the next nblk build lists
-template <bool PRE>
+template <bool PRE, int STEP>
 __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb, char *s_raw)
 {
     LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
@@ -1017,7 +1147,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
-        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
+        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
     } else {
         const int MB = P.M * fr.B;
         const bool lds_cnt = MB <= LPF_BC_LDSCNT;
@@ -1050,7 +1180,7 @@ template <bool PRE>
 __global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
-    lpf_tail_block<PRE>(P, (int)blockIdx.x, s_raw);
+    lpf_tail_block<PRE, 1>(P, (int)blockIdx.x, s_raw);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1076,8 +1206,7 @@ struct LpfTailWideLds {
 template <bool PRE>
 __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const LpfParams P)
 {
-    __shared__ __attribute__((aligned(16))) char s_raw[sizeof(LpfTailWideLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailWideLds) : sizeof(LpfTailListsLds)];
-    LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
+    __shared__ __attribute__((aligned(16))) char s_raw[sizeof(LpfTailWideLds)];
     LpfTailWideLds &LC = *reinterpret_cast<LpfTailWideLds *>(s_raw);
     const int tid = threadIdx.x, lane = lpf_lane(), wave = tid >> 6, tb = (int)blockIdx.x;
     const int ncount = P.count_boxes ? P.nblk : 0;
@@ -1086,7 +1215,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
-        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE>(P, fr, ent.x + wave, LL.lidx[wave]);
+        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);   // (this form: small launches only)
         return;
     }
     const int MB = P.M * fr.B;
@@ -1172,7 +1301,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         const int per = b / plen, pos = b - per * plen;
         if (pos >= Y.kper) {                                // ---- tail of run i-1
             const int tb = per * 8 + (pos - Y.kper);
-            if (tb < Y.ntail) lpf_tail_block<PRE>(Q, tb, s_raw);
+            if (tb < Y.ntail) lpf_tail_block<PRE, 2>(Q, tb, s_raw);
             return;
         }
         vblk = ((per * (Y.kper >> 3) + (pos >> 3)) << 3) | (pos & 7);
