@@ -19,9 +19,10 @@
 // shorter blocks and list waves: a single real frame is 107 segments instead of 27).  Measured on single synthetic clouds
 // (tools/geometry_probe.py, us per step small / large): 1 M 34.9 / 38.7, 2 M 38.5 / 46.9, 3 M 46.0 / 49.5, 4 M 57.1 / 52.0.
 #define LPF_SMALL_LAUNCH (7ll << 19)
-// Tail blocks (of four 1024-point segments) up to which the wide form of the tail runs (measured on copies of sample frame 100:
-// 1 frame = 27 blocks 22.5 vs 25.9 us; 6 frames 29.8 vs 32.8; 8 frames 34.4 vs 35.7; 20 frames = 535 blocks 55.4 vs 49.0 us)
-#define LPF_WIDE_BELOW 220
+// Tail blocks (of four 1024-point segments) up to which the wide form of the tail runs (measured on copies of sample frame 100,
+// wide vs narrow: 4 frames = 108 blocks 21.5 vs 26.8 us; 8 frames 24.2 vs 29.2; 12 frames 29.3 vs 33.0; 20 frames = 540 blocks
+// 41.0 vs 40.6; 32 frames 55.8 vs 50.6)
+#define LPF_WIDE_BELOW 480
 
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_finalize_frame");
 

@@ -40,7 +40,7 @@ def main():
             o.pop("inst_idx")
         if variant == "instonly":
             o.pop("valid_idx")
-        for form in ("small", "large"):
+        for form in (os.environ.get("K2_FORMS", "small,large").split(",")):
             ctx = LpfContext(0)
             ctx.set_stream(stream.cuda_stream)
             ctx.set_camera(T, K3, W, H, 0.0, 50.0)
