@@ -160,8 +160,10 @@ MODES = {
     "partition": (True, True, 32, "pipeline-pack with both side streams confined to 32 CUs (4 per XCD)"),
     "fused": ("fused", False, 0, "software pipelining in one launch per step: the tail of step i-1 and the summaries of step i-2 "
                                  "ride among the streaming tiles of step i"),
+    "fused-pack": ("fused-pack", False, 0, "software pipelining in one launch per step: the mask pack of step i, the streaming tiles of "
+                                           "step i-1, the tail of step i-2 and the summaries of step i-3"),
 }
-DEFAULT_MODE = "fused"
+DEFAULT_MODE = "fused-pack"
 
 
 def launch_ranks(args, argv, dry=False):

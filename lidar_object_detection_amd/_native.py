@@ -291,8 +291,10 @@ class LpfContext:
         """Pipelined device-mode runs (lpf_set_pipelined).  ``on="fused"``: the tail of a run rides in the next run's launch
         (one launch per run, no second stream).  ``on=True``: tail kernels on a second stream; with pack_side the
         device-mode mask packing too (third stream; the masks must be complete when set_masks is called).
-        Results of a run are complete after sync() / release_to_stream()."""
-        mode = 2 if on == "fused" else ((3 if pack_side else 1) if on else 0)
+        ``on="fused-pack"``: as "fused", and the packing of lent uint8 masks rides too -- the launch of a run carries its mask
+        pack, the streaming work of the run before, the tail of the one before that; a run's points and outputs are in use
+        until the launch after the next.  Results of a run are complete after sync() / release_to_stream()."""
+        mode = 4 if on == "fused-pack" else 2 if on == "fused" else ((3 if pack_side else 1) if on else 0)
         self._check(self._lib.lpf_set_pipelined(self._h, mode))
 
     def set_cu_partition(self, side_cus=0, exclusive=False):

@@ -91,7 +91,7 @@ struct lpf_ctx {
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
         hipEvent_t k1_done = nullptr, tail_done = nullptr, mask_done = nullptr;
         bool tail_pending = false, k1_recorded = false, mask_pending = false;
-    } sc[3];
+    } sc[4];
     int parity = 0;
     // Software-pipelined mode (lpf_set_pipelined 2): what earlier runs still owe.  The tail of the last run and the
     // summaries of the one before ride in the next run's launch (lpf_step_t) or are flushed by flush_pending().
@@ -100,8 +100,14 @@ struct lpf_ctx {
         LpfParams P;
         bool pre = false;                 // its prefixes come from the scan kernel
         int ntail = 0;                    // tail blocks
-    } pend_tail, pend_fin;
+        int nk1 = 0, lb = 4;              // (pend_k1) K1 tiles, label element size
+        bool small = false;
+    } pend_k1, pend_tail, pend_fin;
     bool fused = false;
+    // Mode 4: the mask pack rides as well -- the launch of run i carries the pack of run i's masks, the K1 tiles of run i-1
+    // (pend_k1), the tail of run i-2 and the summaries of run i-3; four scratch sets.
+    bool defer = false;
+    struct Ride { bool valid = false; const uint8_t *masks = nullptr; int F = 0, M = 0; void *label = nullptr; } ride;
     int geometry = 0;                 // lpf_set_geometry: 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes
     bool pipelined = false;
     bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
@@ -159,6 +165,18 @@ void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
     else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
 }
 
+// the streaming kernel by itself, in the instantiation the run was laid out for (tile = 256 x rows points)
+void launch_k1(hipStream_t st, const LpfParams &P, int nk1, int lb)
+{
+    const dim3 g((unsigned)nk1), b(LPF_BLOCK);
+    const int rows = P.tile_pts >> 8;
+#define LPF_K1_ROWS(LT) do { if (rows == 2) hipLaunchKernelGGL((lpf_k1_project_t<2, LPF_K1_FLAGS, LT>), g, b, 0, st, P); \
+                             else if (rows == 4) hipLaunchKernelGGL((lpf_k1_project_t<4, LPF_K1_FLAGS, LT>), g, b, 0, st, P); \
+                             else hipLaunchKernelGGL((lpf_k1_project_t<8, LPF_K1_FLAGS, LT>), g, b, 0, st, P); } while (0)
+    if (lb == 1) LPF_K1_ROWS(uint8_t); else if (lb == 2) LPF_K1_ROWS(uint16_t); else LPF_K1_ROWS(uint32_t);
+#undef LPF_K1_ROWS
+}
+
 int flush_pending(lpf_ctx *c)
 {
     if (c->pend_fin.valid) {
@@ -176,12 +194,30 @@ int flush_pending(lpf_ctx *c)
         LPF_HIP(c, hipGetLastError());
         c->pend_tail.valid = false;
     }
+    if (c->pend_k1.valid) {               // mode 4: the last run's streaming kernel has not run yet (its label image is packed)
+        const lpf_ctx::Pending &K = c->pend_k1;
+        if (K.nk1 > 0) {
+            launch_k1(c->stream, K.P, K.nk1, K.lb);
+            LPF_HIP(c, hipGetLastError());
+        }
+        if (K.pre && K.P.nseg_total > 0) {
+            hipLaunchKernelGGL(lpf_scan_segments, dim3(K.P.F), dim3(LPF_BLOCK), 0, c->stream, K.P);
+            LPF_HIP(c, hipGetLastError());
+        }
+        if (K.ntail > 0) {
+            launch_tail(c->stream, K.P, K.ntail, K.pre);
+            LPF_HIP(c, hipGetLastError());
+        }
+        hipLaunchKernelGGL(lpf_finalize, dim3(K.P.F), dim3(LPF_BLOCK), 0, c->stream, K.P);
+        LPF_HIP(c, hipGetLastError());
+        c->pend_k1.valid = false;
+    }
     return LPF_OK;
 }
 
 int sync_all(lpf_ctx *c)                // every stream idle, nothing owed: shared tables / buffers may be rewritten
 {
-    if (!c->capturing && (c->pend_tail.valid || c->pend_fin.valid)) { int rc_ = flush_pending(c); if (rc_) return rc_; }
+    if (!c->capturing && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid)) { int rc_ = flush_pending(c); if (rc_) return rc_; }
     if (c->capturing)
         return fail(c, LPF_ERR_STATE, "this call needs a synchronisation or (re)allocation, which cannot be captured into a graph: "
                                       "run the same shapes once before lpf_graph_begin");
@@ -335,7 +371,7 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "%s: lpf_set_camera must be called first (the candidate grid is per image cell)", who);
     int rc;
     // pipelined modes: the tail of a run already queued / still owed reads the box tables -> drain first
-    if ((c->pipelined || c->pend_tail.valid || c->pend_fin.valid) && !c->capturing && (rc = sync_all(c))) return rc;
+    if ((c->pipelined || c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid) && !c->capturing && (rc = sync_all(c))) return rc;
     const int cw = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT, ch = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     const size_t ncell = (size_t)cw * ch;
     c->h_bframes.resize((size_t)F);
@@ -456,6 +492,15 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         d_masks = (const T *)c->mask_stage.p;
     }
     const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
+    c->ride.valid = false;
+    if (c->defer && per_set && M > 0 && erode_iters == 0 && on_device == 2 && sizeof(T) == 1 && hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
+        // mode 4, lent uint8 masks: packed by blocks of the NEXT lpf_run*'s launch, whose own streaming kernel follows a launch later
+        c->ride.valid = true; c->ride.masks = (const uint8_t *)d_masks; c->ride.F = F; c->ride.M = M; c->ride.label = S.label_a.p;
+        S.label_bytes = lb;
+        S.label_cur = S.label_a.p;
+        c->mask_F = F; c->mask_M = M;
+        return LPF_OK;
+    }
     if (M > 0 && erode_iters == 0 && !c->pipelined && on_device != 1) {
         // serial mode, nothing to erode, and the masks stay where they are (our staging buffer, or lent by the caller):
         // packing is left to the run -- a small launch does without it
@@ -475,6 +520,21 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (pipe) { LPF_HIP(c, hipEventRecord(S.mask_done, ms)); S.mask_pending = true; }
     S.label_cur = cur;
     c->mask_F = F; c->mask_M = M;
+    return LPF_OK;
+}
+
+// mode 4: masks waiting to be packed by the next run's launch -> packed now, by a launch of their own
+int pack_ride_now(lpf_ctx *c)
+{
+    if (!c->ride.valid) return LPF_OK;
+    const long long hw = (long long)c->H * c->W, total16 = (long long)c->ride.F * (hw / 16);
+    const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+    const int M = c->ride.M, lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
+    if (lb == 1) hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint8_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint8_t *)c->ride.label, M, hw, total16);
+    else if (lb == 2) hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint16_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint16_t *)c->ride.label, M, hw, total16);
+    else hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint32_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint32_t *)c->ride.label, M, hw, total16);
+    LPF_HIP(c, hipGetLastError());
+    c->ride.valid = false;
     return LPF_OK;
 }
 
@@ -669,8 +729,8 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (on < 0 || on > 3) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 2 the tail rides in the next run's launch, "
-                                                      "3 = 1 + mask packing on a side stream)", on);
+    if (on < 0 || on > 4) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 2 the tail rides in the next run's launch, "
+                                                      "3 = 1 + mask packing on a side stream, 4 = 2 + the mask pack rides as well)", on);
     int rc = sync_all(c);
     if (rc) return rc;
     if ((rc = ensure_packed(c))) return rc;
@@ -684,7 +744,9 @@ int lpf_set_pipelined(lpf_ctx *c, int on)
         }
     }
     c->pipelined = on != 0;
-    c->fused = on == 2;
+    c->fused = on == 2 || on == 4;
+    c->defer = on == 4;
+    c->ride.valid = false;
     c->pack_side = on == 3;
     c->parity = 0;
     ++c->generation;
@@ -716,7 +778,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
     // pipelined modes: the tail of a run already queued / still owed counts boxes with the OLD camera's candidate grid
-    if (!c->capturing && (c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending)) {
+    if (!c->capturing && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending)) {
         if (use_device(c)) return LPF_ERR_HIP;
         int rc_ = sync_all(c);
         if (rc_) return rc_;
@@ -770,6 +832,7 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
     if (use_device(c)) return LPF_ERR_HIP;
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     { int rc_ = ensure_packed(c); if (rc_) return rc_; }
+    { int rc_ = pack_ride_now(c); if (rc_) return rc_; }
     lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
     if (!S.label_cur || !c->mask_F) return fail(c, LPF_ERR_STATE, "no masks set");
     const size_t npix = (size_t)c->mask_F * c->H * c->W;
@@ -922,7 +985,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool pipe_any = c->pipelined && !host_io && pts_on_device && !c->capturing;
     const bool fused = pipe_any && c->fused;               // the tail rides in the next run's launch (three scratch sets)
     const bool pipe = pipe_any && !c->fused;               // the tail runs on a second stream (two scratch sets)
-    if (!pipe_any && (c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c)))
+    if (!pipe_any && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c)))
         return rc;                                         // set 0 is used with every stream idle and nothing owed
     lpf_ctx::Scratch &S = c->sc[pipe_any ? c->parity : 0];
     hipStream_t tail_stream = pipe ? c->stream_b : c->stream;
@@ -945,6 +1008,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap; P.ngrp_cap = ngrp_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
+    if (c->ride.valid && !fused && (rc = pack_ride_now(c))) return rc;     // (a host-memory run in mode 4: no launch for the pack to ride in)
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
     const bool direct = M > 0 && c->lazy.valid && small && !pipe_any;
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
@@ -1053,49 +1117,66 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipEventRecord(e0, c->stream));
     }
     if (fused) {
-        // ---- one launch: this run's K1 tiles, the previous run's tail blocks dealt out among them, the summaries of the
-        //      run before that (lpf_step_t) ----------------------------------------------------------------------------
+        // ---- one launch (lpf_step_t): K1 tiles, the tail blocks of the run before dealt out among them, the summaries of the
+        //      run before that.  Mode 2: the tiles are this run's.  Mode 4: this run's MASK PACK rides as well (lent uint8 masks),
+        //      the tiles are the previous run's -- everything one launch later, nothing left on the stream between two steps.
+        lpf_ctx::Pending cur;
+        cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
+        const bool ride = c->defer && c->ride.valid && M > 0;
+        if (c->defer && c->pend_k1.valid && ride && c->pend_k1.lb != lb && (rc = flush_pending(c))) return rc;   // one label element type per launch
+        const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur;
         const lpf_ctx::Pending &Q = c->pend_tail, &R = c->pend_fin;
+        const LpfParams &KP = KK.valid ? KK.P : P;
+        const int k_lb = KK.valid ? KK.lb : lb;
         LpfStepLayout Y;
+        LpfPackJob J;
+        memset(&J, 0, sizeof J);
         Y.nfin = R.valid ? R.P.F : 0;
         Y.nfin8 = (Y.nfin + 7) & ~7;
         Y.ntail = Q.valid ? Q.ntail : 0;
-        Y.nk1 = nk1;
-        const int nk1_pad = (nk1 + 7) & ~7;
+        Y.nk1 = KK.valid ? KK.nk1 : 0;
+        Y.npack = 0;
+        if (ride) {
+            J.masks = c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
+            J.total16 = (long long)c->ride.F * (J.hw / 16);
+            Y.npack = (int)((J.total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+        }
+        const int nk1_pad = (Y.nk1 + 7) & ~7;
         Y.nper = (Y.ntail + 7) / 8;
         Y.kper = 8;
-        if (Y.nper > 0) {                                  // spread the tail blocks over the first two thirds of the tiles (same box,
+        if (Y.nper > 0) {                                  // spread the side blocks over the first two thirds of the tiles (same box,
             // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5:
             // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)
             const long long k = ((long long)nk1_pad * 13 / 20 / 8) / Y.nper;
             Y.kper = (int)(k < 1 ? 1 : k) * 8;
         }
         const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
-        const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + (rest > 0 ? rest : 0);
+        Y.rest = (int)(rest > 0 ? rest : 0);
+        const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
         if (grid > 0) {
             const dim3 gs((unsigned)grid);
             const LpfParams &QP = Q.valid ? Q.P : P, &RP = R.valid ? R.P : P;      // unused roles get a well-formed struct
-#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, P, QP, RP, Y)
-#define LPF_STEP_LT(RW, PR) do { if (lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
+#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J)
+#define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
             const bool qpre = Q.valid && Q.pre;
-            if (small) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
-            else if (P.tile_pts == 2048) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
+            const int rows = KP.tile_pts >> 8;
+            if (rows == 2) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
+            else if (rows == 8) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
             else       { if (qpre) LPF_STEP_LT(4, true); else LPF_STEP_LT(4, false); }
 #undef LPF_STEP_LT
 #undef LPF_STEP_LAUNCH
             LPF_HIP(c, hipGetLastError());
         }
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
-        if (pre_scan && nseg_total > 0) {                  // frames beyond 64 groups: their prefixes are scanned before the tail rides
-            hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
+        if (KK.valid && KK.pre && KK.P.nseg_total > 0) {   // frames beyond 64 groups: their prefixes are scanned before the tail rides
+            hipLaunchKernelGGL(lpf_scan_segments, dim3(KK.P.F), dim3(LPF_BLOCK), 0, c->stream, KK.P);
             LPF_HIP(c, hipGetLastError());
         }
         c->pend_fin = c->pend_tail;                        // its tail has just been launched: summaries in a later launch
-        c->pend_tail.valid = true;
-        c->pend_tail.P = P;
-        c->pend_tail.pre = pre_scan;
-        c->pend_tail.ntail = ntail;
-        c->parity = (c->parity + 1) % 3;
+        c->pend_tail = KK;
+        if (c->defer) c->pend_k1 = cur;
+        c->ride.valid = false;
+        c->parity = (c->parity + 1) % (c->defer ? 4 : 3);
         return LPF_OK;
     }
     if (nk1 > 0) {

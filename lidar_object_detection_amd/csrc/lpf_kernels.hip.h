@@ -1277,12 +1277,24 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 struct LpfStepLayout {
     int nfin, nfin8;             // summary blocks (frames of run i-2), padded
     int ntail;                   // tail blocks of run i-1
-    int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
+    int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry side blocks (tail, then pack)
     int nk1;                     // K1 tiles of run i
+    int npack;                   // mask-pack blocks (mode 4: of the run whose K1 tiles the NEXT launch carries), after all K1 tiles
+    int rest;                    // K1 block slots after the periods
 };
+struct LpfPackJob {              // uint8 masks [F][M][H][W] -> label image [F][H][W] of the step's LT (lpf_pack16_block)
+    const uint8_t *masks;
+    void *label;
+    long long hw, total16;
+    int M;
+};
+template <typename T, int MODE, typename LT>
+__device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
+                                                 const int M, const long long hw, const long long total16, const long long blk);
 
 template <int ROWS, unsigned FL, typename LT, bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y)
+__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y,
+                                                           const LpfPackJob J)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
@@ -1299,7 +1311,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     int vblk;                                               // K1: virtual block index, (rank on the XCD) << 3 | XCD
     if (b < periodic) {
         const int per = b / plen, pos = b - per * plen;
-        if (pos >= Y.kper) {                                // ---- tail of run i-1
+        if (pos >= Y.kper) {                                // ---- tail of run i-1, then the mask pack (mode 4)
             const int tb = per * 8 + (pos - Y.kper);
             if (tb < Y.ntail) lpf_tail_block<PRE, 2>(Q, tb, s_raw);
             return;
@@ -1307,6 +1319,10 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         vblk = ((per * (Y.kper >> 3) + (pos >> 3)) << 3) | (pos & 7);
     } else {
         const int r = b - periodic;
+        if (r >= Y.rest) {                                  // ---- the mask pack (mode 4): behind the tiles, it fills their ramp-down
+            if (r - Y.rest < Y.npack) lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest);
+            return;
+        }
         vblk = ((Y.nper * (Y.kper >> 3) + (r >> 3)) << 3) | (r & 7);
     }
     // ---- K1 tile of run i: XCD x owns a contiguous run of count_x tiles (lpf_xcd_remap); the grid is padded per XCD
@@ -1592,10 +1608,10 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_setup_kernel(const LpfBoxSe
 // (float masks 4 x 16 bytes), the packed labels leave as four 16-byte stores.
 // Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).
 template <typename T, int MODE, typename LT>
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, LT *__restrict__ label,
-                                                        int M, long long hw, long long total16)
+__device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
+                                                 const int M, const long long hw, const long long total16, const long long blk)
 {
-    const long long g = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;    // group of 16 pixels, over all frames
+    const long long g = blk * LPF_BLOCK + threadIdx.x;      // group of 16 pixels, over all frames
     if (g >= total16) return;
     const long long per_frame = hw >> 4;
     const long long f = g / per_frame, o = (g - f * per_frame) << 4;
@@ -1658,6 +1674,13 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ ma
         for (int k = 0; k < 4; ++k)
             reinterpret_cast<uint4 *>(dst)[k] = make_uint4(bits[4 * k], bits[4 * k + 1], bits[4 * k + 2], bits[4 * k + 3]);
     }
+}
+
+template <typename T, int MODE, typename LT>
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, LT *__restrict__ label,
+                                                        int M, long long hw, long long total16)
+{
+    lpf_pack16_block<T, MODE, LT>(masks, label, M, hw, total16, (long long)blockIdx.x);
 }
 
 // General-shape pack with optional fused first erosion: 64x16 output tile per block,

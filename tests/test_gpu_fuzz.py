@@ -80,8 +80,9 @@ def test_fuzz_against_oracle(seed, form, calib):
             assert np.array_equal(r[k], o[k], equal_nan=True), (seed, form, f, k)
 
 
+@pytest.mark.parametrize("mode", ["fused", "fused-pack"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24")) // 2))
-def test_fuzz_software_pipelined_device_mode(seed, calib):
+def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
     """The same random cases through device mode under lpf_set_pipelined(2), three consecutive cases per context with nothing
     synchronised in between: the tail of case k rides in the launch of case k+1 (another shape, other masks and boxes), its
     summaries in the launch of case k+2."""
@@ -92,7 +93,7 @@ def test_fuzz_software_pipelined_device_mode(seed, calib):
     cases = [_case(base + 3 * seed + j, calib) for j in range(3)]
     held = []
     with LpfContext(0) as ctx:
-        ctx.set_pipelined("fused")
+        ctx.set_pipelined(mode)
         for T, K, W, H, dmax, oriented, M, frames, masks, boxes in cases:
             F = len(frames)
             sizes = [len(p) for p in frames]
@@ -111,7 +112,7 @@ def test_fuzz_software_pipelined_device_mode(seed, calib):
             torch.cuda.synchronize(dev)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
-                ctx.set_masks(mt)
+                ctx.set_masks(mt, lend=mode == "fused-pack")
             else:
                 ctx.clear_masks()
             ctx.set_boxes(boxes, oriented=oriented)

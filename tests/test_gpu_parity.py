@@ -377,7 +377,7 @@ def test_full_size_properties_2m(ctx, calib):
     _compare(r, o, 8, want_float=False)
 
 
-@pytest.mark.parametrize("pipelined", [False, True, "fused", "pack_side", "cus32", "cus64_exclusive_pack_side"])
+@pytest.mark.parametrize("pipelined", [False, True, "fused", "fused-pack", "pack_side", "cus32", "cus64_exclusive_pack_side"])
 def test_device_mode_back_to_back_runs(calib, pipelined):
     """Device-pointer mode (torch tensors): several different batches enqueued back to back without
     host syncs, with and without the tail kernels on a second stream (optionally with the mask pack on a third, and
@@ -394,7 +394,7 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         if pipelined == "cus32":
             ctx.set_cu_partition(32)
-    ctx.set_pipelined("fused" if pipelined == "fused" else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
+    ctx.set_pipelined(pipelined if pipelined in ("fused", "fused-pack") else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     F, M, Bx = 3, 5, 7
     runs = []
@@ -413,7 +413,7 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
     ctx.set_boxes([sc["corners_velo"] for sc in runs[0][0]])       # same boxes for every run (tables are per context)
     torch.cuda.synchronize(dev)
     for scenes, sizes, off, pts, masks, o in runs:
-        ctx.set_masks(masks)
+        ctx.set_masks(masks, lend=pipelined == "fused-pack")       # lent masks: their pack rides in the run's launch (mode 4)
         ctx.run_device(pts, off, inst_cap=int(off[-1]), **o)
     ctx.sync()
     torch.cuda.synchronize(dev)

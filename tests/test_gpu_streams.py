@@ -131,7 +131,8 @@ def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
         del make
 
 
-def test_software_pipelined_mode_across_state_changes(calib):
+@pytest.mark.parametrize("mode", ["fused", "fused-pack"])
+def test_software_pipelined_mode_across_state_changes(calib, mode):
     """lpf_set_pipelined(2): the tail of a run rides in the NEXT run's launch and its summaries in the one after.  Whatever
     changes between two runs -- camera window, boxes, masks and their count, batch shape, launch geometry -- the owed work
     must be finished with the state it was queued under.  Nothing is synchronised by the test until every run is queued."""
@@ -146,7 +147,7 @@ def test_software_pipelined_mode_across_state_changes(calib):
         ([70_001, 5, 300], 2, 11, 20.0, "large-scan"), ([12_345], 0, 0, 20.0, "auto"), ([12_345], 3, 5, 20.0, "auto")]
     runs = []
     with LpfContext(0) as ctx:
-        ctx.set_pipelined("fused")
+        ctx.set_pipelined(mode)
         for k, (sizes, M, Bx, dmax, geo) in enumerate(plan):
             scenes = [S.scene(max(n, 1), n_masks=max(M, 1), n_boxes=max(Bx, 1), seed=300 + 10 * k + f) for f, n in enumerate(sizes)]
             F, n = len(sizes), int(sum(sizes))
@@ -161,7 +162,7 @@ def test_software_pipelined_mode_across_state_changes(calib):
             ctx.set_geometry(geo)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
-                ctx.set_masks(masks)
+                ctx.set_masks(masks, lend=mode == "fused-pack")
             else:
                 ctx.clear_masks()
             if Bx:

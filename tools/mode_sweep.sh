@@ -17,8 +17,8 @@ print("%-28s %7.2f us/step  K1 bracket %6.2f us  (step frac %.3f)" % (sys.argv[2
 PY
 }
 if [ "${1:-}" = "quick" ]; then
-run serial --mode serial && run fused --mode fused && run pipeline --mode pipeline
+run serial --mode serial && run fused --mode fused && run fused_pack --mode fused-pack && run pipeline --mode pipeline
 else
-run serial --mode serial && run fused --mode fused && run pipeline --mode pipeline && run pipeline_pack --mode pipeline-pack && \
+run serial --mode serial && run fused --mode fused && run fused_pack --mode fused-pack && run pipeline --mode pipeline && run pipeline_pack --mode pipeline-pack && \
 run part32 --mode partition --side-cus 32 && run part64 --mode partition --side-cus 64 && run part64x --mode partition --side-cus 64 --exclusive
 fi
