@@ -286,7 +286,7 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
 
             def fused_loop(step_fn, check):
                 """the same step in a loop under the software-pipelined mode (a stream of batches: throughput, not latency)"""
-                ctx.set_pipelined("fused")
+                ctx.set_pipelined("fused-pack")
                 for _ in range(3):
                     step_fn()
                 ctx.sync()
@@ -593,18 +593,24 @@ def main():
         if k1_n:
             dur_s = 1e-3 * k1_ms / k1_n                              # mean event bracket around the kernel
             achieved = ALGO_BYTES_PER_POINT * ntot / dur_s / 1e9
-            traffic, traffic_note = pmc_traffic(ntot, "lpf_step_t" if args.mode == "fused" else "lpf_k1_project_t")
+            step_kernel = args.mode in ("fused", "fused-pack")
+            traffic, traffic_note = pmc_traffic(ntot, "lpf_step_t" if step_kernel else "lpf_k1_project_t")
             # SURVEY 8(d) asks for both figures: the strict 28 B per input point (-> achieved, frac) and the itemised total
             # of what this launch produces: + 4 B label-image gather per valid point and, when the launch carries the list
-            # blocks too (the fused step), + 8 B valid_idx per valid point + 8 B per instance-list entry
+            # blocks too (the fused step), + 8 B valid_idx per valid point + 8 B per instance-list entry; when it carries the
+            # mask pack as well (fused-pack), + the masks read and the label images written
             itemised = None
             if "n_valid_batch" in main_run:
                 itemised = ALGO_BYTES_PER_POINT * ntot + 4 * main_run["n_valid_batch"]
-                if args.mode == "fused":
+                if step_kernel:
                     itemised += 8 * main_run["n_valid_batch"] + 8 * main_run["n_list_entries_batch"]
+                if args.mode == "fused-pack":
+                    itemised += F * (N_MASKS + 1) * W * H
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                                "kernel": "lpf_step_t (project+label tiles of this step + tail blocks of the previous one)" if args.mode == "fused"
+                                "kernel": "lpf_step_t (mask pack of this step + project+label tiles of the previous one + tail blocks of the one before)"
+                                if args.mode == "fused-pack" else
+                                "lpf_step_t (project+label tiles of this step + tail blocks of the previous one)" if args.mode == "fused"
                                 else "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "empty_bracket_us": 1e3 * empty_ms,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,

@@ -32,9 +32,10 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 3          /* 2: lpf_outputs gained uv_valid / label_valid
+#define LPF_ABI_VERSION 4          /* 2: lpf_outputs gained uv_valid / label_valid
                                       3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
-                                         lpf_set_pipelined modes; lpf_set_cu_partition; stale graphs are refused */
+                                         lpf_set_pipelined modes; lpf_set_cu_partition; stale graphs are refused
+                                      4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4); lpf_set_geometry */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -112,6 +113,12 @@ int  lpf_sync(lpf_ctx *ctx);
  * streaming tiles, and the per-frame summaries of run i-2; three scratch sets rotate, nothing in a launch depends on
  * anything else in it, no second stream and no event is involved.  What is still owed is launched by lpf_sync(),
  * lpf_release_to_stream() or any call that changes the context's state.
+ * on = 4: as 2, and the MASK PACK rides as well, so that nothing is left on the stream between two launches: the launch
+ * made by run i carries the pack of run i's masks (uint8 masks lent with on_device = 2 and no erosion; other masks are
+ * packed by their own launch as before), the streaming kernel of run i-1 -- its label images were packed one launch
+ * earlier -- the tail of run i-2 and the summaries of run i-3; the pack blocks come behind the streaming tiles and fill
+ * their ramp-down (16 M-point step: 92 us instead of 98).  Four scratch sets rotate.  A run's POINTS are read, and its
+ * outputs written, by the launch of the NEXT run (or by lpf_sync / lpf_release_to_stream): keep them untouched until then.
  * on = 1: the short tail kernels of a run (index lists, box counts,
  * per-frame summary) execute on a second, internal stream and overlap the streaming kernel of
  * the next run, which uses a second set of scratch buffers.  on = 3: in addition device-mode

@@ -23,6 +23,10 @@
 // wide vs narrow: 4 frames = 108 blocks 21.5 vs 26.8 us; 8 frames 24.2 vs 29.2; 12 frames 29.3 vs 33.0; 20 frames = 540 blocks
 // 41.0 vs 40.6; 32 frames 55.8 vs 50.6)
 #define LPF_WIDE_BELOW 480
+// Share of a step launch's K1 tiles (in twentieths) among which the previous run's tail blocks are dealt (see lpf_run_batch)
+#ifndef LPF_TAIL_SPREAD_20THS
+#define LPF_TAIL_SPREAD_20THS 13
+#endif
 
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_finalize_frame");
 
@@ -1105,7 +1109,11 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool want_lists = out->valid_idx || out->inst_idx;
     const int ntail = nblk * ((count_boxes ? 1 : 0) + (want_lists ? 1 : 0));      // no lists wanted and no boxes: no tail blocks at all
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if ((nk1 > 0 || fused) && c->profiling && c->ev_used < (1u << 16)) {
+    // mode 4: the mask pack and the tiles of one launch share the label element type -- else the pipeline is drained first
+    if (fused && c->defer && c->pend_k1.valid && c->ride.valid && M > 0 && c->pend_k1.lb != lb && (rc = flush_pending(c))) return rc;
+    // (profiling brackets the launches that carry streaming tiles: in mode 4 the first launch after a drain carries none)
+    const bool carries_k1 = (fused && c->defer) ? (c->pend_k1.valid && c->pend_k1.nk1 > 0) : (nk1 > 0 || fused);
+    if (carries_k1 && c->profiling && c->ev_used < (1u << 16)) {
         if (c->ev.size() < 2 * (c->ev_used + 1)) {
             hipEvent_t a, b;
             LPF_HIP(c, hipEventCreate(&a));
@@ -1123,7 +1131,6 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         lpf_ctx::Pending cur;
         cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
         const bool ride = c->defer && c->ride.valid && M > 0;
-        if (c->defer && c->pend_k1.valid && ride && c->pend_k1.lb != lb && (rc = flush_pending(c))) return rc;   // one label element type per launch
         const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur;
         const lpf_ctx::Pending &Q = c->pend_tail, &R = c->pend_fin;
         const LpfParams &KP = KK.valid ? KK.P : P;
@@ -1147,7 +1154,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         if (Y.nper > 0) {                                  // spread the side blocks over the first two thirds of the tiles (same box,
             // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5:
             // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)
-            const long long k = ((long long)nk1_pad * 13 / 20 / 8) / Y.nper;
+            const long long k = ((long long)nk1_pad * LPF_TAIL_SPREAD_20THS / 20 / 8) / Y.nper;
             Y.kper = (int)(k < 1 ? 1 : k) * 8;
         }
         const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;

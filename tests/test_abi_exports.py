@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_native.EXPORTED) == names
     lib.lpf_abi_version.restype = ctypes.c_int
-    assert lib.lpf_abi_version() == 3
+    assert lib.lpf_abi_version() == 4
 
 
 def test_struct_mirrors():
