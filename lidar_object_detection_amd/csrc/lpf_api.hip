@@ -162,58 +162,78 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                     \
     } while (0)
 
-// software-pipelined mode: launch what earlier runs still owe, on the context's stream
+// the narrow tail kernel (serial and stream-pipelined modes)
 void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
 {
     if (pre) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
     else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
 }
 
-// the streaming kernel by itself, in the instantiation the run was laid out for (tile = 256 x rows points)
-void launch_k1(hipStream_t st, const LpfParams &P, int nk1, int lb)
+// One launch of lpf_step_t: the streaming tiles of run K, the tail blocks of run Q dealt out among them, the summaries of
+// run R and -- mode 4 -- the pack of the masks waiting in c->ride behind the tiles (label elements of pack_lb bytes; K's when
+// K is there: the host keeps the two equal).  Any of the roles may be absent.  `after` is recorded behind the launch.
+int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &Q, const lpf_ctx::Pending &R, bool ride, int pack_lb,
+                hipEvent_t after)
 {
-    const dim3 g((unsigned)nk1), b(LPF_BLOCK);
-    const int rows = P.tile_pts >> 8;
-#define LPF_K1_ROWS(LT) do { if (rows == 2) hipLaunchKernelGGL((lpf_k1_project_t<2, LPF_K1_FLAGS, LT>), g, b, 0, st, P); \
-                             else if (rows == 4) hipLaunchKernelGGL((lpf_k1_project_t<4, LPF_K1_FLAGS, LT>), g, b, 0, st, P); \
-                             else hipLaunchKernelGGL((lpf_k1_project_t<8, LPF_K1_FLAGS, LT>), g, b, 0, st, P); } while (0)
-    if (lb == 1) LPF_K1_ROWS(uint8_t); else if (lb == 2) LPF_K1_ROWS(uint16_t); else LPF_K1_ROWS(uint32_t);
-#undef LPF_K1_ROWS
+    static const LpfParams none = {};                      // unused roles get a well-formed struct
+    const LpfParams &KP = KK.valid ? KK.P : none, &QP = Q.valid ? Q.P : none, &RP = R.valid ? R.P : none;
+    const int k_lb = KK.valid ? KK.lb : pack_lb;
+    LpfStepLayout Y;
+    LpfPackJob J;
+    memset(&J, 0, sizeof J);
+    Y.nfin = R.valid ? R.P.F : 0;
+    Y.nfin8 = (Y.nfin + 7) & ~7;
+    Y.ntail = Q.valid ? Q.ntail : 0;
+    Y.nk1 = KK.valid ? KK.nk1 : 0;
+    Y.npack = 0;
+    if (ride) {
+        J.masks = c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
+        J.total16 = (long long)c->ride.F * (J.hw / 16);
+        Y.npack = (int)((J.total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+    }
+    const int nk1_pad = (Y.nk1 + 7) & ~7;
+    Y.nper = (Y.ntail + 7) / 8;
+    Y.kper = 8;
+    if (Y.nper > 0) {                                      // spread the tail blocks over the first two thirds of the tiles (same box,
+        // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5;
+        // again with the pack riding, 40 / 50 / 65 / 80 / 95 %: 95.4 / 95.6-95.9 / 91.4-92.0 / 93.2-93.3 / 93.9:
+        // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)
+        const long long k = ((long long)nk1_pad * LPF_TAIL_SPREAD_20THS / 20 / 8) / Y.nper;
+        Y.kper = (int)(k < 1 ? 1 : k) * 8;
+    }
+    const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
+    Y.rest = (int)(rest > 0 ? rest : 0);
+    const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
+    if (grid > 0) {
+        const dim3 gs((unsigned)grid);
+#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J)
+#define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
+        const bool qpre = Q.valid && Q.pre;
+        const int rows = KP.tile_pts >> 8;
+        if (rows == 2) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
+        else if (rows == 8) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
+        else       { if (qpre) LPF_STEP_LT(4, true); else LPF_STEP_LT(4, false); }
+#undef LPF_STEP_LT
+#undef LPF_STEP_LAUNCH
+        LPF_HIP(c, hipGetLastError());
+    }
+    if (after) LPF_HIP(c, hipEventRecord(after, c->stream));
+    if (KK.valid && KK.pre && KK.P.nseg_total > 0) {       // frames beyond 64 groups: their prefixes are scanned before the tail rides
+        hipLaunchKernelGGL(lpf_scan_segments, dim3(KK.P.F), dim3(LPF_BLOCK), 0, c->stream, KK.P);
+        LPF_HIP(c, hipGetLastError());
+    }
+    return LPF_OK;
 }
 
+// software-pipelined modes: launch what earlier runs still owe -- the same step launches, with fewer roles each time
 int flush_pending(lpf_ctx *c)
 {
-    if (c->pend_fin.valid) {
-        hipLaunchKernelGGL(lpf_finalize, dim3(c->pend_fin.P.F), dim3(LPF_BLOCK), 0, c->stream, c->pend_fin.P);
-        LPF_HIP(c, hipGetLastError());
-        c->pend_fin.valid = false;
-    }
-    if (c->pend_tail.valid) {
-        const lpf_ctx::Pending &T = c->pend_tail;
-        if (T.ntail > 0) {
-            launch_tail(c->stream, T.P, T.ntail, T.pre);
-            LPF_HIP(c, hipGetLastError());
-        }
-        hipLaunchKernelGGL(lpf_finalize, dim3(T.P.F), dim3(LPF_BLOCK), 0, c->stream, T.P);
-        LPF_HIP(c, hipGetLastError());
-        c->pend_tail.valid = false;
-    }
-    if (c->pend_k1.valid) {               // mode 4: the last run's streaming kernel has not run yet (its label image is packed)
-        const lpf_ctx::Pending &K = c->pend_k1;
-        if (K.nk1 > 0) {
-            launch_k1(c->stream, K.P, K.nk1, K.lb);
-            LPF_HIP(c, hipGetLastError());
-        }
-        if (K.pre && K.P.nseg_total > 0) {
-            hipLaunchKernelGGL(lpf_scan_segments, dim3(K.P.F), dim3(LPF_BLOCK), 0, c->stream, K.P);
-            LPF_HIP(c, hipGetLastError());
-        }
-        if (K.ntail > 0) {
-            launch_tail(c->stream, K.P, K.ntail, K.pre);
-            LPF_HIP(c, hipGetLastError());
-        }
-        hipLaunchKernelGGL(lpf_finalize, dim3(K.P.F), dim3(LPF_BLOCK), 0, c->stream, K.P);
-        LPF_HIP(c, hipGetLastError());
+    while (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid) {
+        const lpf_ctx::Pending K = c->pend_k1, Q = c->pend_tail, R = c->pend_fin;
+        int rc_ = launch_step(c, K, Q, R, false, 4, nullptr);
+        if (rc_) return rc_;
+        c->pend_fin = Q;                   // its tail has just been launched: summaries next
+        c->pend_tail = K;
         c->pend_k1.valid = false;
     }
     return LPF_OK;
@@ -1130,56 +1150,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         //      the tiles are the previous run's -- everything one launch later, nothing left on the stream between two steps.
         lpf_ctx::Pending cur;
         cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
-        const bool ride = c->defer && c->ride.valid && M > 0;
-        const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur;
-        const lpf_ctx::Pending &Q = c->pend_tail, &R = c->pend_fin;
-        const LpfParams &KP = KK.valid ? KK.P : P;
-        const int k_lb = KK.valid ? KK.lb : lb;
-        LpfStepLayout Y;
-        LpfPackJob J;
-        memset(&J, 0, sizeof J);
-        Y.nfin = R.valid ? R.P.F : 0;
-        Y.nfin8 = (Y.nfin + 7) & ~7;
-        Y.ntail = Q.valid ? Q.ntail : 0;
-        Y.nk1 = KK.valid ? KK.nk1 : 0;
-        Y.npack = 0;
-        if (ride) {
-            J.masks = c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
-            J.total16 = (long long)c->ride.F * (J.hw / 16);
-            Y.npack = (int)((J.total16 + LPF_BLOCK - 1) / LPF_BLOCK);
-        }
-        const int nk1_pad = (Y.nk1 + 7) & ~7;
-        Y.nper = (Y.ntail + 7) / 8;
-        Y.kper = 8;
-        if (Y.nper > 0) {                                  // spread the side blocks over the first two thirds of the tiles (same box,
-            // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5:
-            // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)
-            const long long k = ((long long)nk1_pad * LPF_TAIL_SPREAD_20THS / 20 / 8) / Y.nper;
-            Y.kper = (int)(k < 1 ? 1 : k) * 8;
-        }
-        const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
-        Y.rest = (int)(rest > 0 ? rest : 0);
-        const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
-        if (grid > 0) {
-            const dim3 gs((unsigned)grid);
-            const LpfParams &QP = Q.valid ? Q.P : P, &RP = R.valid ? R.P : P;      // unused roles get a well-formed struct
-#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J)
-#define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
-            const bool qpre = Q.valid && Q.pre;
-            const int rows = KP.tile_pts >> 8;
-            if (rows == 2) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
-            else if (rows == 8) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
-            else       { if (qpre) LPF_STEP_LT(4, true); else LPF_STEP_LT(4, false); }
-#undef LPF_STEP_LT
-#undef LPF_STEP_LAUNCH
-            LPF_HIP(c, hipGetLastError());
-        }
-        if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
-        if (KK.valid && KK.pre && KK.P.nseg_total > 0) {   // frames beyond 64 groups: their prefixes are scanned before the tail rides
-            hipLaunchKernelGGL(lpf_scan_segments, dim3(KK.P.F), dim3(LPF_BLOCK), 0, c->stream, KK.P);
-            LPF_HIP(c, hipGetLastError());
-        }
-        c->pend_fin = c->pend_tail;                        // its tail has just been launched: summaries in a later launch
+        const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur, Q = c->pend_tail, R = c->pend_fin;
+        if ((rc = launch_step(c, KK, Q, R, c->defer && c->ride.valid && M > 0, lb, e1))) return rc;
+        c->pend_fin = Q;                                   // its tail has just been launched: summaries in a later launch
         c->pend_tail = KK;
         if (c->defer) c->pend_k1 = cur;
         c->ride.valid = false;
