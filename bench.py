@@ -74,9 +74,12 @@ def pmc_traffic(points_per_launch, kernel="lpf_k1_project_t"):
     if meta.get("kernel_source_sha16") != kernel_source_sha():
         return None, "profiles/%s was collected on kernel sources %s, these are %s: re-run tools/refresh_profiles.sh" % (
             PMC_FILE, meta.get("kernel_source_sha16"), kernel_source_sha())
-    for k, v in d.items():
-        if kernel in k:
-            return v["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, kernel sources %s)" % (PMC_FILE, kernel_source_sha())
+    # (the step kernel has several instantiations in a run: the one launched most is the steady-state step -- the others are
+    #  the pipeline's first launch, which carries only a mask pack, and the drain's)
+    hits = [(v.get("launches", 0), k, v) for k, v in d.items() if k != "_meta" and kernel in k]
+    if hits:
+        _, k, v = max(hits, key=lambda t: t[0])
+        return v["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc, kernel sources %s, %s)" % (PMC_FILE, kernel_source_sha(), k.split("(")[0])
     return None, "profiles/%s has no entry for %s" % (PMC_FILE, kernel)
 
 
