@@ -63,6 +63,7 @@ struct lpf_ctx {
 
     // masks -> label images
     int mask_F = 0, mask_M = 0;       // 0 frames = no masks set
+    int mask_set = 0;                 // the scratch set whose label image holds them
     DevBuf mask_stage;
     // Masks not packed yet (serial mode, no erosion, host masks in mask_stage or device masks the caller lends: on_device 2):
     // a small launch reads them directly in K1 (LpfDirect), anything else packs them first (ensure_packed).
@@ -502,6 +503,7 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     lpf_ctx::Scratch &S = c->sc[per_set ? c->parity : 0];
     hipStream_t ms = pipe ? c->stream_c : c->stream;
     c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
+    c->mask_set = per_set ? c->parity : 0;
     if (F == 0) return LPF_OK;
     const size_t hw = (size_t)c->H * c->W;
     if ((rc = reserve(c, S.label_a, (size_t)F * hw * 4))) return rc;
@@ -839,6 +841,7 @@ int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_
     if ((rc = sync_all(c))) return rc;
     lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
     c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
+    c->mask_set = c->pipelined ? c->parity : 0;
     if (F == 0) return LPF_OK;
     const size_t bytes = (size_t)F * c->H * c->W * 4;
     if ((rc = reserve(c, S.label_a, bytes))) return rc;
@@ -857,7 +860,7 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
     { int rc_ = sync_all(c); if (rc_) return rc_; }
     { int rc_ = ensure_packed(c); if (rc_) return rc_; }
     { int rc_ = pack_ride_now(c); if (rc_) return rc_; }
-    lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
+    lpf_ctx::Scratch &S = c->sc[c->mask_set];
     if (!S.label_cur || !c->mask_F) return fail(c, LPF_ERR_STATE, "no masks set");
     const size_t npix = (size_t)c->mask_F * c->H * c->W;
     if (S.label_bytes == 4) {
@@ -1036,7 +1039,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
     const bool direct = M > 0 && c->lazy.valid && small && !pipe_any;
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
-    P.label_img = (M > 0) ? (direct ? c->lazy.p : S.label_cur) : nullptr;
+    // The label image lives in the scratch set that was current when the masks were set.  A pipelined run must find it in its
+    // own set (the sets rotate: masks are set before every run); any other run has every stream idle and reads it where it is.
+    const lpf_ctx::Scratch &SM = c->sc[c->mask_set];
+    if (M > 0 && pipe_any && !direct && c->mask_set != c->parity)
+        return fail(c, LPF_ERR_STATE, "the masks were set for another scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
+    P.label_img = (M > 0) ? (direct ? c->lazy.p : SM.label_cur) : nullptr;
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
@@ -1125,7 +1133,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // per wave, so the streaming work holds its bandwidth on fewer resident blocks (measured: 104.9 vs 108.8 us per step)
     if (fused && !small) P.tile_pts = 2048;
     const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
-    const int lb = (M > 0) ? S.label_bytes : 4;
+    const int lb = (M > 0) ? SM.label_bytes : 4;
     const bool want_lists = out->valid_idx || out->inst_idx;
     const int ntail = nblk * ((count_boxes ? 1 : 0) + (want_lists ? 1 : 0));      // no lists wanted and no boxes: no tail blocks at all
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -192,3 +192,65 @@ def test_software_pipelined_mode_across_state_changes(calib, mode):
                 assert np.array_equal(cmb[M * boff:M * (boff + Bx)].reshape(M, Bx), ref["count_mb"])
                 assert np.array_equal(sm[f]["best_box"][:M], ref["best_box"]) and np.array_equal(sm[f]["best_cnt"][:M], ref["best_cnt"])
             boff += Bx
+
+
+def test_pack_riding_mode_corner_cases(calib):
+    """lpf_set_pipelined(4): the pack of lent uint8 masks rides in the run's launch, the run's streaming kernel in the next.
+    Corners: the masks' element width changes between consecutive runs (pack and tiles of one launch share it: the pipeline
+    is drained first), a run with float masks or an erosion (packed by their own launch), a run without masks, the label image
+    read back while a pack is still waiting for its launch, and a host-memory run in between (no launch to ride in)."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    n, Bx = 30_000, 6
+    plan = [(5, "u8", 0), (5, "u8", 0), (12, "u8", 0), (20, "u8", 0), (3, "f32", 0), (4, "u8", 1), (0, "u8", 0), (7, "u8", 0), (7, "u8", 0)]
+    runs = []
+    with LpfContext(0) as ctx:
+        ctx.set_pipelined("fused-pack")
+        ctx.set_camera(T, K, W, H, 0.0, 30.0)
+        sc0 = S.scene(n, n_masks=1, n_boxes=Bx, seed=900)
+        ctx.set_boxes([sc0["corners_velo"]])
+        for k, (M, kind, erode) in enumerate(plan):
+            sc = S.scene(n, n_masks=max(M, 1), n_boxes=Bx, seed=901 + k)
+            member = sc["masks"][:M]
+            o = _outputs(torch, dev, n, max(M, 1), Bx, SUMMARY_DTYPE.itemsize)
+            pts = torch.from_numpy(sc["points"]).to(dev)
+            m = None
+            if M:
+                m = torch.from_numpy(member.astype(np.float32) if kind == "f32" else member).to(dev)
+            torch.cuda.synchronize(dev)
+            if M:
+                ctx.set_masks(m, erode_iters=erode, lend=True)
+            else:
+                ctx.clear_masks()
+            ctx.run_device(pts, np.array([0, n], np.int64), inst_cap=n, **o)
+            runs.append((sc, M, erode, o, pts, m))
+        ctx.sync()
+        for sc, M, erode, o, pts, m in runs:
+            sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
+            limg = orc.pack_masks(sc["masks"][:M], erode, H, W) if M else None
+            ref = orc.run(sc["points"], T, K, W, H, 0.0, 30.0, label_img=limg, M=M, corners=sc0["corners_velo"], want_float=False)
+            assert int(sm["n_valid"]) == ref["n_valid"]
+            assert np.array_equal(o["valid_idx"][:ref["n_valid"]].cpu().numpy(), ref["valid_idx"])
+            assert np.array_equal(o["label_bits"].cpu().numpy().view(np.uint32), ref["label_bits"])
+            if M:
+                assert np.array_equal(sm["inst_count"][:M], ref["inst_count"])
+                assert np.array_equal(o["count_mb"][:M * Bx].cpu().numpy().reshape(M, Bx), ref["count_mb"])
+        # a pack still waiting for its launch when the label image is asked for: packed now
+        sc = S.scene(n, n_masks=6, n_boxes=Bx, seed=950)
+        m = torch.from_numpy(sc["masks"]).to(dev)
+        torch.cuda.synchronize(dev)
+        ctx.set_masks(m, lend=True)
+        assert np.array_equal(ctx.get_label_image()[0], orc.pack_masks(sc["masks"], 0, H, W))
+        # ... and a host-memory run right after lent masks were set (it does not go through the step launch)
+        ctx.set_masks(m, lend=True)
+        try:
+            r = ctx.run(sc["points"])
+        except Exception as e:                              # the label images rotate with the scratch sets: a loud refusal is fine too
+            assert "masks" in str(e)
+        else:
+            ref = orc.run(sc["points"], T, K, W, H, 0.0, 30.0, label_img=orc.pack_masks(sc["masks"], 0, H, W), M=6,
+                          corners=sc0["corners_velo"], want_float=False)
+            assert np.array_equal(r["label_bits"], ref["label_bits"]) and np.array_equal(r["count_mb"], ref["count_mb"])
