@@ -250,10 +250,24 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         ms, cnt = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
         k1_us = 1e3 * ms / max(cnt, 1)
+        # the same clouds as a software-pipelined stream (one launch per cloud: its mask pack, the previous cloud's
+        # project+label tiles, the tail of the one before): throughput of a stream of single clouds, not latency
+        ctx.set_pipelined("fused-pack")
+        for f_ in fns:
+            f_()
+        ctx.sync()
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
+        if not (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(o["count_mb"].cpu().numpy().reshape(N_MASKS, N_BOXES), ref["count_mb"])
+                and np.array_equal(o["valid_idx"][:ref["n_valid"]].cpu().numpy(), ref["valid_idx"])):
+            raise SystemExit("bench secondary configs[2], pipelined stream: GPU result differs from the CPU oracle")
+        dt_p = time_steps(torch, dev, fns, 300, 30, lambda: (ctx.sync(), sync()))
+        ctx.set_pipelined(False)
         out["configs2_one_2M_cloud_per_launch"] = {
             "points_per_s": n / dt, "us_per_step": 1e6 * dt, "k1_bracket_us": k1_us,
             "k1_algorithmic_GBps": ALGO_BYTES_PER_POINT * n / (k1_us * 1e-6) / 1e9,
             "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * n / dt / 1e9 / HBM_PEAK_GBS,
+            "us_per_step_software_pipelined": 1e6 * dt_p, "points_per_s_software_pipelined": n / dt_p,
+            "step_algorithmic_frac_of_hbm_peak_software_pipelined": ALGO_BYTES_PER_POINT * n / dt_p / 1e9 / HBM_PEAK_GBS,
             "checked": "n_valid, valid_idx, u, v, label_bits, count_mb == CPU oracle"}
         del bufs, fns
 
