@@ -47,15 +47,19 @@ def main():
             if variant not in ("noboxes", "bare", "validonly", "instonly"):
                 ctx.set_boxes([corners] * F)
             ctx.set_geometry(form)
+            if os.environ.get("K2_PIPE"):                    # e.g. fused-pack: a software-pipelined stream of such steps
+                ctx.set_pipelined(os.environ["K2_PIPE"])
             step = ctx.make_device_step(d_pts, off, masks_u8=d_masks, erode_iters=0, inst_cap=n, **o)
             for _ in range(20):
                 step()
+            ctx.sync()
             stream.synchronize()
             cm = o["count_mb"].cpu().numpy().reshape(F, M, B)
             assert variant in ("noboxes", "bare", "validonly", "instonly") or all(np.array_equal(cm[f], g["count_mb_rect5_d50"]) for f in range(F))
             t0 = time.perf_counter()
             for _ in range(500):
                 step()
+            ctx.sync()
             stream.synchronize()
             res[form] = (time.perf_counter() - t0) / 500 * 1e6
             ctx.close()
