@@ -29,6 +29,7 @@ python3 "$R/tools/pmc_summary.py" "$O" pmc_fused-pack pmc_serial "$O/${TAG}_pmc_
 echo "[3b] bench default again, now that the counter file of these sources exists (roofline.traffic)"
 cp "$O/${TAG}_pmc_bench_f8x2M.json" "$R/profiles/${TAG}_pmc_bench_f8x2M.json"
 timeout -k 10 400 python3 "$R/bench.py" > "$O/${TAG}_bench_default.json" 2> "$O/bench_default.err" || echo "bench failed"
+timeout -k 10 300 python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-secondary > "$O/${TAG}_bench_driver_args.json" 2> "$O/bench_driver_args.err" || echo "driver-args bench failed"
 echo "[4] probes"
 timeout -k 10 200 python3 "$R/tools/frame100_bench.py" > "$O/${TAG}_frame100_configs01.json" 2> /dev/null
 timeout -k 10 200 python3 "$R/tools/k2_probe.py" 20 2> /dev/null | tee "$O/${TAG}_k2_probe_20frames.txt"
