@@ -98,8 +98,9 @@ struct lpf_ctx {
         bool tail_pending = false, k1_recorded = false, mask_pending = false;
     } sc[4];
     int parity = 0;
-    // Software-pipelined mode (lpf_set_pipelined 2): what earlier runs still owe.  The tail of the last run and the
-    // summaries of the one before ride in the next run's launch (lpf_step_t) or are flushed by flush_pending().
+    // Software-pipelined modes (lpf_set_pipelined 2 / 4): what earlier runs still owe.  The tail of the last run and the
+    // summaries of the one before ride in the next run's launch (lpf_step_t) -- in mode 4 the last run's streaming kernel
+    // too (pend_k1) -- or are launched by flush_pending().
     struct Pending {
         bool valid = false;
         LpfParams P;
@@ -1008,9 +1009,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // (16.7 M points) take their prefixes from the scan kernel instead
     const bool pre_scan = max_ngrp > 64 || c->geometry == 3;
 
-    // pipelined device runs alternate between two scratch sets; everything else uses set 0 with both streams idle
+    // pipelined device runs rotate through the scratch sets (2, 3 or 4 by mode); everything else uses set 0 with every stream idle
     const bool pipe_any = c->pipelined && !host_io && pts_on_device && !c->capturing;
-    const bool fused = pipe_any && c->fused;               // the tail rides in the next run's launch (three scratch sets)
+    const bool fused = pipe_any && c->fused;               // the tail rides in the next run's launch (three scratch sets; four in mode 4)
     const bool pipe = pipe_any && !c->fused;               // the tail runs on a second stream (two scratch sets)
     if (!pipe_any && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c)))
         return rc;                                         // set 0 is used with every stream idle and nothing owed

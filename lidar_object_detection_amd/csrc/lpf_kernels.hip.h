@@ -1263,21 +1263,24 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 }
 
 // ------------------------------------------------------------------------------------
-// STEP (software-pipelined mode): ONE launch carries the streaming kernel of run i, the tail of run i-1 and the
-// summaries of run i-2 -- three scratch sets, so nothing in a launch depends on anything else in it; the launch
+// STEP (software-pipelined modes): ONE launch carries the streaming kernel of run i, the tail of run i-1 and the
+// summaries of run i-2 -- and, in mode 4, the mask pack of run i+1, whose own streaming kernel the next launch
+// carries.  One scratch set per run in flight, so nothing in a launch depends on anything else in it; the launch
 // boundaries order the runs' phases.  The tail's ~2000 short, latency-bound blocks are dealt out among the K1
 // tiles, eight (one per XCD) after every `kper` tiles, so they trickle through the chip beside the streaming
-// work instead of standing in front of it or behind it:
+// work instead of standing in front of it or behind it; the pack's ~1000 blocks are pure streaming work and come
+// last, where they run while the final tiles drain (dealt among the tiles they cost what they take):
 //     blocks [0, nfin8)                               summaries of run i-2 (nfin8 = frames, padded to a multiple of 8)
 //     then nper periods of (kper K1 tiles, 8 tail blocks)
 //     then the remaining K1 tiles
+//     then the pack blocks
 // A K1 block's XCD is blockIdx & 7 throughout (every offset is a multiple of 8), which lpf_k1_tile's tile
 // mapping relies on (speed only).
 // ------------------------------------------------------------------------------------
 struct LpfStepLayout {
     int nfin, nfin8;             // summary blocks (frames of run i-2), padded
     int ntail;                   // tail blocks of run i-1
-    int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry side blocks (tail, then pack)
+    int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
     int nk1;                     // K1 tiles of run i
     int npack;                   // mask-pack blocks (mode 4: of the run whose K1 tiles the NEXT launch carries), after all K1 tiles
     int rest;                    // K1 block slots after the periods

@@ -1,13 +1,25 @@
 #!/bin/bash
 # Regenerates the measured artifacts under profiles/ on the GPU box (run through gpurun; outputs land in
 # gpurun_out/refresh/, copy them into profiles/ afterwards).  Counter passes are separate runs with
-# --kernel-trace only, as the pool requires.   usage: tools/refresh_profiles.sh [round tag, default r02]
+# --kernel-trace only, as the pool requires.   usage: tools/refresh_profiles.sh [round tag, default r02] [pmc]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r02}
 O=$R/gpurun_out/refresh
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+PMC_ONLY=${2:-}          # "pmc": only the counter passes and the bench lines that quote them (after a source change that moves no time)
+if [ "$PMC_ONLY" = pmc ]; then
+  for M in fused-pack serial; do for C in FETCH_SIZE WRITE_SIZE; do
+    echo "[pmc] $M $C"; timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_${M}_$C" -- python3 "$R/bench.py" --mode $M --steps 20 --warmup 4 --no-cpu --no-secondary --no-events > /dev/null 2> "$O/pmc_${M}_$C.err"; echo "rocprofv3 exit $?"
+  done; done
+  python3 "$R/tools/pmc_summary.py" "$O" pmc_fused-pack pmc_serial "$O/${TAG}_pmc_bench_f8x2M.json" || exit 1
+  cp "$O/${TAG}_pmc_bench_f8x2M.json" "$R/profiles/${TAG}_pmc_bench_f8x2M.json"
+  timeout -k 10 400 python3 "$R/bench.py" > "$O/${TAG}_bench_default.json" 2> "$O/bench_default.err" || echo "bench failed"
+  timeout -k 10 300 python3 "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-secondary > "$O/${TAG}_bench_driver_args.json" 2> "$O/bench_driver_args.err" || echo "driver-args bench failed"
+  tail -c 300 "$O/${TAG}_bench_driver_args.json"; echo
+  exit 0
+fi
 echo "[1] bench default (fused-pack queueing) with the secondary configs and the CPU baseline"
 timeout -k 10 400 python3 "$R/bench.py" > "$O/${TAG}_bench_default.json" 2> "$O/bench_default.err" || echo "bench failed"
 tail -c 300 "$O/${TAG}_bench_default.json"; echo
