@@ -47,3 +47,27 @@ def test_a_launched_rank_does_not_relaunch():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--no-cpu"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "needs an MI355X" in (out.stdout + out.stderr)
+
+
+def test_pmc_traffic_takes_the_steady_state_step_kernel(tmp_path, monkeypatch):
+    """The step kernel shows up in several instantiations in a counter pass (the pipeline's first launch carries only a
+    mask pack, the drain's launches only tails and summaries): roofline.traffic quotes the one launched most, and
+    nothing at all when the pass ran other kernel sources or another launch size."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    data = {"_meta": {"kernel_source_sha16": "abc", "points_per_launch": 16_000_000},
+            "void lpf_step_t<4, 7u, unsigned char, false>": {"launches": 2, "hbm_bytes_per_launch": 38e6},
+            "void lpf_step_t<8, 7u, unsigned char, false>": {"launches": 24, "hbm_bytes_per_launch": 516e6},
+            "void lpf_step_t<4, 7u, unsigned int, false>": {"launches": 4, "hbm_bytes_per_launch": 9e6},
+            "void lpf_k1_project_t<4, 7u, unsigned char>": {"launches": 24, "hbm_bytes_per_launch": 464e6}}
+    (prof / bench.PMC_FILE).write_text(json.dumps(data))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "abc")
+    assert bench.pmc_traffic(16_000_000, "lpf_step_t")[0] == 516e6
+    assert bench.pmc_traffic(16_000_000, "lpf_k1_project_t")[0] == 464e6
+    assert bench.pmc_traffic(2_000_000, "lpf_step_t")[0] is None
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "other")
+    got, why = bench.pmc_traffic(16_000_000, "lpf_step_t")
+    assert got is None and "re-run" in why
