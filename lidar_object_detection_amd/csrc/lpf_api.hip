@@ -108,12 +108,16 @@ struct lpf_ctx {
         int ntail = 0;                    // tail blocks
         int nk1 = 0, lb = 4;              // (pend_k1) K1 tiles, label element size
         bool small = false;
+        bool direct = false;              // its tiles read the lent masks themselves (LpfDirect; small launches)
+        int dsel = 0;                     // ... under membership rule 0 (uint8) or 1..3 (float)
     } pend_k1, pend_tail, pend_fin;
     bool fused = false;
     // Mode 4: the mask pack rides as well -- the launch of run i carries the pack of run i's masks, the K1 tiles of run i-1
     // (pend_k1), the tail of run i-2 and the summaries of run i-3; four scratch sets.
     bool defer = false;
-    struct Ride { bool valid = false; const uint8_t *masks = nullptr; int F = 0, M = 0; void *label = nullptr; } ride;
+    // Lent masks of a software-pipelined context that have not been packed: the next run decides -- a small launch reads them
+    // directly, a large one in mode 4 lets their pack ride in its launch (uint8, 16-byte aligned planes), anything else packs now.
+    struct Ride { bool valid = false; const void *masks = nullptr; bool f32 = false, can_ride = false; int mode = 0, F = 0, M = 0; void *label = nullptr; } ride;
     int geometry = 0;                 // lpf_set_geometry: 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes
     bool pipelined = false;
     bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
@@ -189,7 +193,7 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     Y.nk1 = KK.valid ? KK.nk1 : 0;
     Y.npack = 0;
     if (ride) {
-        J.masks = c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
+        J.masks = (const uint8_t *)c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
         J.total16 = (long long)c->ride.F * (J.hw / 16);
         Y.npack = (int)((J.total16 + LPF_BLOCK - 1) / LPF_BLOCK);
     }
@@ -212,6 +216,12 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
 #define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
         const bool qpre = Q.valid && Q.pre;
         const int rows = KP.tile_pts >> 8;
+        if (KK.valid && KK.direct) {                       // small launch whose tiles read the lent masks themselves (no pack role beside it)
+            typedef LpfDirect<uint8_t, 0> D0; typedef LpfDirect<float, 1> D1; typedef LpfDirect<float, 2> D2; typedef LpfDirect<float, 3> D3;
+#define LPF_STEP_DIRECT(D) do { if (qpre) LPF_STEP_LAUNCH(2, D, true); else LPF_STEP_LAUNCH(2, D, false); } while (0)
+            if (KK.dsel == 0) LPF_STEP_DIRECT(D0); else if (KK.dsel == 1) LPF_STEP_DIRECT(D1); else if (KK.dsel == 2) LPF_STEP_DIRECT(D2); else LPF_STEP_DIRECT(D3);
+#undef LPF_STEP_DIRECT
+        } else
         if (rows == 2) { if (qpre) LPF_STEP_LT(2, true); else LPF_STEP_LT(2, false); }
         else if (rows == 8) { if (qpre) LPF_STEP_LT(8, true); else LPF_STEP_LT(8, false); }
         else       { if (qpre) LPF_STEP_LT(4, true); else LPF_STEP_LT(4, false); }
@@ -520,9 +530,11 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     }
     const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
     c->ride.valid = false;
-    if (c->defer && per_set && M > 0 && erode_iters == 0 && on_device == 2 && sizeof(T) == 1 && hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0) {
-        // mode 4, lent uint8 masks: packed by blocks of the NEXT lpf_run*'s launch, whose own streaming kernel follows a launch later
-        c->ride.valid = true; c->ride.masks = (const uint8_t *)d_masks; c->ride.F = F; c->ride.M = M; c->ride.label = S.label_a.p;
+    if (c->fused && per_set && M > 0 && erode_iters == 0 && on_device == 2) {
+        // software-pipelined modes, lent masks: left to the next lpf_run* (see lpf_ctx::Ride)
+        c->ride.valid = true; c->ride.masks = d_masks; c->ride.F = F; c->ride.M = M; c->ride.label = S.label_a.p;
+        c->ride.f32 = sizeof(T) == 4; c->ride.mode = mode;
+        c->ride.can_ride = c->defer && sizeof(T) == 1 && hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0;
         S.label_bytes = lb;
         S.label_cur = S.label_a.p;
         c->mask_F = F; c->mask_M = M;
@@ -550,42 +562,44 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     return LPF_OK;
 }
 
-// mode 4: masks waiting to be packed by the next run's launch -> packed now, by a launch of their own
+// masks [F][M][H][W] (uint8 under rule 0, or float under rule mode) -> label image of scratch set S, by a launch of their own
+int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32, int mode, int F, int M)
+{
+    const int lb = S.label_bytes;
+    void *cur = nullptr;
+    int rc;
+    if (f32) {
+        const float *m = (const float *)masks;
+        if (lb == 1) rc = pack_typed<float, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        else if (lb == 2) rc = pack_typed<float, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+    } else {
+        const uint8_t *m = (const uint8_t *)masks;
+        if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        else if (lb == 2) rc = pack_typed<uint8_t, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        else rc = pack_typed<uint8_t, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+    }
+    if (rc) return rc;
+    S.label_cur = cur;
+    return LPF_OK;
+}
+
+// lent masks of a pipelined context still unpacked (lpf_ctx::Ride) -> packed now
 int pack_ride_now(lpf_ctx *c)
 {
     if (!c->ride.valid) return LPF_OK;
-    const long long hw = (long long)c->H * c->W, total16 = (long long)c->ride.F * (hw / 16);
-    const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
-    const int M = c->ride.M, lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
-    if (lb == 1) hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint8_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint8_t *)c->ride.label, M, hw, total16);
-    else if (lb == 2) hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint16_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint16_t *)c->ride.label, M, hw, total16);
-    else hipLaunchKernelGGL((lpf_pack16<uint8_t, 0, uint32_t>), dim3(nb), dim3(LPF_BLOCK), 0, c->stream, c->ride.masks, (uint32_t *)c->ride.label, M, hw, total16);
-    LPF_HIP(c, hipGetLastError());
+    int rc = pack_masks_now(c, c->sc[c->mask_set], c->ride.masks, c->ride.f32, c->ride.mode, c->ride.F, c->ride.M);
+    if (rc) return rc;
     c->ride.valid = false;
     return LPF_OK;
 }
 
-// masks left unpacked by lpf_set_masks_* -> label image of scratch set 0, on the main stream
+// masks left unpacked by lpf_set_masks_* in serial mode (lpf_ctx::Lazy) -> label image of scratch set 0
 int ensure_packed(lpf_ctx *c)
 {
     if (!c->lazy.valid) return LPF_OK;
-    lpf_ctx::Scratch &S = c->sc[0];
-    const int F = c->mask_F, M = c->mask_M, lb = S.label_bytes;
-    void *cur = nullptr;
-    int rc;
-    if (c->lazy.f32) {
-        const float *m = (const float *)c->lazy.p;
-        if (lb == 1) rc = pack_typed<float, uint8_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-        else if (lb == 2) rc = pack_typed<float, uint16_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-        else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-    } else {
-        const uint8_t *m = (const uint8_t *)c->lazy.p;
-        if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-        else if (lb == 2) rc = pack_typed<uint8_t, uint16_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-        else rc = pack_typed<uint8_t, uint32_t>(c, S, c->stream, m, F, M, c->lazy.mode, 0, &cur);
-    }
+    int rc = pack_masks_now(c, c->sc[0], c->lazy.p, c->lazy.f32, c->lazy.mode, c->mask_F, c->mask_M);
     if (rc) return rc;
-    S.label_cur = cur;
     c->lazy.valid = false;
     return LPF_OK;
 }
@@ -1036,7 +1050,11 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap; P.ngrp_cap = ngrp_cap;
     P.oriented = c->oriented; P.inst_cap = out->inst_cap;
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
-    if (c->ride.valid && !fused && (rc = pack_ride_now(c))) return rc;     // (a host-memory run in mode 4: no launch for the pack to ride in)
+    // lent masks of a pipelined context (lpf_ctx::Ride): a small fused launch reads them directly, a large one in mode 4 carries
+    // their pack, anything else (mode 2, float masks, a host-memory run) packs them now
+    const bool direct_fused = c->ride.valid && fused && small && M > 0;
+    const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
+    if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
     const bool direct = M > 0 && c->lazy.valid && small && !pipe_any;
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
@@ -1045,7 +1063,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const lpf_ctx::Scratch &SM = c->sc[c->mask_set];
     if (M > 0 && pipe_any && !direct && c->mask_set != c->parity)
         return fail(c, LPF_ERR_STATE, "the masks were set for another scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
-    P.label_img = (M > 0) ? (direct ? c->lazy.p : SM.label_cur) : nullptr;
+    P.label_img = (M > 0) ? (direct ? c->lazy.p : direct_fused ? c->ride.masks : SM.label_cur) : nullptr;
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
     P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
@@ -1139,7 +1157,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const int ntail = nblk * ((count_boxes ? 1 : 0) + (want_lists ? 1 : 0));      // no lists wanted and no boxes: no tail blocks at all
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // mode 4: the mask pack and the tiles of one launch share the label element type -- else the pipeline is drained first
-    if (fused && c->defer && c->pend_k1.valid && c->ride.valid && M > 0 && c->pend_k1.lb != lb && (rc = flush_pending(c))) return rc;
+    if (fused && c->defer && c->pend_k1.valid && ride_pack && (c->pend_k1.direct || c->pend_k1.lb != lb) && (rc = flush_pending(c))) return rc;
     // (profiling brackets the launches that carry streaming tiles: in mode 4 the first launch after a drain carries none)
     const bool carries_k1 = (fused && c->defer) ? (c->pend_k1.valid && c->pend_k1.nk1 > 0) : (nk1 > 0 || fused);
     if (carries_k1 && c->profiling && c->ev_used < (1u << 16)) {
@@ -1159,8 +1177,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         //      the tiles are the previous run's -- everything one launch later, nothing left on the stream between two steps.
         lpf_ctx::Pending cur;
         cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
+        cur.direct = direct_fused; cur.dsel = c->ride.f32 ? c->ride.mode : 0;
         const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur, Q = c->pend_tail, R = c->pend_fin;
-        if ((rc = launch_step(c, KK, Q, R, c->defer && c->ride.valid && M > 0, lb, e1))) return rc;
+        if ((rc = launch_step(c, KK, Q, R, ride_pack, lb, e1))) return rc;
         c->pend_fin = Q;                                   // its tail has just been launched: summaries in a later launch
         c->pend_tail = KK;
         if (c->defer) c->pend_k1 = cur;

@@ -221,6 +221,8 @@ __device__ __forceinline__ bool lpf_member(T v)
 }
 
 template <typename T, int MODE> struct LpfDirect { };        // tag: label bits straight from masks of element T under rule MODE
+template <typename LT> struct LpfIsDirect { static constexpr bool value = false; };
+template <typename T, int MODE> struct LpfIsDirect<LpfDirect<T, MODE> > { static constexpr bool value = true; };
 
 template <typename LT>
 struct LpfLabelSrc {                                         // packed label image [F][H][W] of LT
@@ -1323,7 +1325,9 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     } else {
         const int r = b - periodic;
         if (r >= Y.rest) {                                  // ---- the mask pack (mode 4): behind the tiles, it fills their ramp-down
-            if (r - Y.rest < Y.npack) lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest);
+            if constexpr (!LpfIsDirect<LT>::value) {        // (tiles that read the masks directly never share a launch with a pack)
+                if (r - Y.rest < Y.npack) lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest);
+            }
             return;
         }
         vblk = ((Y.nper * (Y.kper >> 3) + (r >> 3)) << 3) | (r & 7);

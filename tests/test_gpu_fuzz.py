@@ -80,7 +80,7 @@ def test_fuzz_against_oracle(seed, form, calib):
             assert np.array_equal(r[k], o[k], equal_nan=True), (seed, form, f, k)
 
 
-@pytest.mark.parametrize("mode", ["fused", "fused-pack"])
+@pytest.mark.parametrize("mode", ["fused", "fused+lent", "fused-pack+lent"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24")) // 2))
 def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
     """The same random cases through device mode under lpf_set_pipelined(2), three consecutive cases per context with nothing
@@ -93,7 +93,7 @@ def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
     cases = [_case(base + 3 * seed + j, calib) for j in range(3)]
     held = []
     with LpfContext(0) as ctx:
-        ctx.set_pipelined(mode)
+        ctx.set_pipelined(mode.split("+")[0])
         for T, K, W, H, dmax, oriented, M, frames, masks, boxes in cases:
             F = len(frames)
             sizes = [len(p) for p in frames]
@@ -112,7 +112,7 @@ def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
             torch.cuda.synchronize(dev)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
-                ctx.set_masks(mt, lend=mode == "fused-pack")
+                ctx.set_masks(mt, lend="+lent" in mode)
             else:
                 ctx.clear_masks()
             ctx.set_boxes(boxes, oriented=oriented)

@@ -377,7 +377,8 @@ def test_full_size_properties_2m(ctx, calib):
     _compare(r, o, 8, want_float=False)
 
 
-@pytest.mark.parametrize("pipelined", [False, True, "fused", "fused-pack", "pack_side", "cus32", "cus64_exclusive_pack_side"])
+@pytest.mark.parametrize("pipelined", [False, True, "fused", "fused+lent", "fused+lent+large", "fused-pack", "fused-pack+lent", "fused-pack+lent+large",
+                                       "pack_side", "cus32", "cus64_exclusive_pack_side"])
 def test_device_mode_back_to_back_runs(calib, pipelined):
     """Device-pointer mode (torch tensors): several different batches enqueued back to back without
     host syncs, with and without the tail kernels on a second stream (optionally with the mask pack on a third, and
@@ -394,7 +395,13 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         if pipelined == "cus32":
             ctx.set_cu_partition(32)
-    ctx.set_pipelined(pipelined if pipelined in ("fused", "fused-pack") else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
+    # software-pipelined modes: masks packed at the call / lent (a small launch's tiles then read them directly; with the large
+    # geometry forced, mode 4 lets their pack ride in the run's launch and mode 2 packs them by a launch of its own)
+    fmode = pipelined.split("+")[0] if isinstance(pipelined, str) and pipelined.startswith("fused") else None
+    lent = isinstance(pipelined, str) and "+lent" in pipelined
+    if fmode and pipelined.endswith("+large"):
+        ctx.set_geometry("large")
+    ctx.set_pipelined(fmode if fmode else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     F, M, Bx = 3, 5, 7
     runs = []
@@ -413,7 +420,7 @@ def test_device_mode_back_to_back_runs(calib, pipelined):
     ctx.set_boxes([sc["corners_velo"] for sc in runs[0][0]])       # same boxes for every run (tables are per context)
     torch.cuda.synchronize(dev)
     for scenes, sizes, off, pts, masks, o in runs:
-        ctx.set_masks(masks, lend=pipelined == "fused-pack")       # lent masks: their pack rides in the run's launch (mode 4)
+        ctx.set_masks(masks, lend=lent)
         ctx.run_device(pts, off, inst_cap=int(off[-1]), **o)
     ctx.sync()
     torch.cuda.synchronize(dev)

@@ -131,7 +131,7 @@ def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
         del make
 
 
-@pytest.mark.parametrize("mode", ["fused", "fused-pack"])
+@pytest.mark.parametrize("mode", ["fused", "fused+lent", "fused-pack", "fused-pack+lent"])
 def test_software_pipelined_mode_across_state_changes(calib, mode):
     """lpf_set_pipelined(2): the tail of a run rides in the NEXT run's launch and its summaries in the one after.  Whatever
     changes between two runs -- camera window, boxes, masks and their count, batch shape, launch geometry -- the owed work
@@ -147,7 +147,7 @@ def test_software_pipelined_mode_across_state_changes(calib, mode):
         ([70_001, 5, 300], 2, 11, 20.0, "large-scan"), ([12_345], 0, 0, 20.0, "auto"), ([12_345], 3, 5, 20.0, "auto")]
     runs = []
     with LpfContext(0) as ctx:
-        ctx.set_pipelined(mode)
+        ctx.set_pipelined(mode.split("+")[0])
         for k, (sizes, M, Bx, dmax, geo) in enumerate(plan):
             scenes = [S.scene(max(n, 1), n_masks=max(M, 1), n_boxes=max(Bx, 1), seed=300 + 10 * k + f) for f, n in enumerate(sizes)]
             F, n = len(sizes), int(sum(sizes))
@@ -162,7 +162,7 @@ def test_software_pipelined_mode_across_state_changes(calib, mode):
             ctx.set_geometry(geo)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
-                ctx.set_masks(masks, lend=mode == "fused-pack")
+                ctx.set_masks(masks, lend="+lent" in mode)   # lent: read directly by a small launch's tiles, or packed by blocks of a large one
             else:
                 ctx.clear_masks()
             if Bx:
