@@ -165,7 +165,9 @@ int lpf_set_camera(lpf_ctx *ctx, const double T_velo_to_rect[16], const double K
  *   stays unchanged until every run that uses these masks has completed.  Lent masks (and host masks, which sit in the
  *   context's own staging buffer) that need no erosion are not packed at the call in serial mode: a small launch (a real
  *   frame or a few) then looks a valid point's M mask values up directly -- ~20 k points x M bytes instead of a separate
- *   4.7 us launch over 530 k pixels x M -- and a large one packs them first, on the same stream.  Same results. */
+ *   4.7 us launch over 530 k pixels x M -- and a large one packs them first, on the same stream.  The software-pipelined
+ *   modes (lpf_set_pipelined 2 / 4) leave lent masks to the next lpf_run* in the same way: a small launch's tiles read
+ *   them directly, a large one packs them (mode 4: by blocks of its own launch, see there).  Same results. */
 int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode_iters, int on_device);
 int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int binarize,
                       int erode_iters, int on_device);

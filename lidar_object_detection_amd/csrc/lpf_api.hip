@@ -1052,11 +1052,15 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
     // lent masks of a pipelined context (lpf_ctx::Ride): a small fused launch reads them directly, a large one in mode 4 carries
     // their pack, anything else (mode 2, float masks, a host-memory run) packs them now
-    const bool direct_fused = c->ride.valid && fused && small && M > 0;
+    // (directly: M gathers per valid point against M reads per pixel for the pack -- it pays while a frame has fewer points than
+    //  half its image has pixels: a real scan, 110 k points on 530 k pixels, 29.9 -> 24.9 us per 20-frame batch in a pipelined
+    //  stream; a synthetic 2 M-point cloud is better off with the pack riding, 21.8 vs 24.2 us)
+    const bool sparse_frames = Ntot * 2 <= (int64_t)F * c->W * c->H;
+    const bool direct_fused = c->ride.valid && fused && small && sparse_frames && M > 0;
     const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
     if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
-    const bool direct = M > 0 && c->lazy.valid && small && !pipe_any;
+    const bool direct = M > 0 && c->lazy.valid && small && sparse_frames && !pipe_any;
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
     // The label image lives in the scratch set that was current when the masks were set.  A pipelined run must find it in its
     // own set (the sets rotate: masks are set before every run); any other run has every stream idle and reads it where it is.
