@@ -5,10 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path (mask pack -> project+label -> index lists + box
-counts -> per-frame summary) over one batch of synthetic clouds of BASELINE.json
+One step = one pass of the hot path (box preparation -> mask pack -> project+label -> index
+lists + box counts -> per-frame summary) over one batch of synthetic clouds of BASELINE.json
 configs[2]'s shape: --frames clouds (default 8) of 2 M points, each with 8 disk masks and
-32 boxes, V4 clip (depth < 30), processed by one batched launch set.  Inputs are resident
+32 boxes, V4 clip (depth < 30), processed by one batched launch set.  Like the reference's
+frame loop (V3:556-562) every step brings its OWN boxes: their cam-0 corners are lent in HBM,
+filter_visible_bboxes + transform_bboxes_to_velodyne + the table set-up run on the device
+inside the step (--static-boxes sets them once instead).  Inputs are resident
 in HBM before the timed region; every step touches > 256 MiB and the resident batches are
 cycled, so the traffic is real HBM traffic, not Infinity-Cache hits.  The timed region
 runs twice: once plain (-> value) and once with HIP events around the project+label
@@ -46,7 +49,7 @@ ALGO_BYTES_PER_POINT = 28          # 16 B xyzI read + 8 B (u,v) write + 4 B labe
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-PMC_FILE = "r02_pmc_bench_f8x2M.json"
+PMC_FILE = "r03_pmc_bench_f8x2M.json"
 
 
 def kernel_source_sha():
@@ -155,16 +158,13 @@ def cpu_baseline(scene, T, K, W, H, budget_s):
     return out
 
 
-# How a step's kernels are queued (name -> tail overlaps next step, pack on a side stream, CUs of the side streams, text)
+# How a step's kernels are queued (name -> lpf_set_pipelined argument, text)
 MODES = {
-    "serial": (False, False, 0, "every kernel of a step on one stream, in order"),
-    "pipeline": (True, False, 0, "tail kernels (scan, lists, finalize) of step i on a second stream, overlapping step i+1"),
-    "pipeline-pack": (True, True, 0, "pipeline + the mask pack of step i+1 on a third stream"),
-    "partition": (True, True, 32, "pipeline-pack with both side streams confined to 32 CUs (4 per XCD)"),
-    "fused": ("fused", False, 0, "software pipelining in one launch per step: the tail of step i-1 and the summaries of step i-2 "
-                                 "ride among the streaming tiles of step i"),
-    "fused-pack": ("fused-pack", False, 0, "software pipelining in one launch per step: the mask pack of step i, the streaming tiles of "
-                                           "step i-1, the tail of step i-2 and the summaries of step i-3"),
+    "serial": (False, "every kernel of a step on one stream, in order"),
+    "fused": ("fused", "software pipelining in one launch per step: the tail of step i-1 and the summaries of step i-2 "
+                       "ride among the streaming tiles of step i"),
+    "fused-pack": ("fused-pack", "software pipelining in one launch per step: the mask pack and box set-up of step i, the streaming "
+                                 "tiles of step i-1, the tail of step i-2 and the summaries of step i-3"),
 }
 DEFAULT_MODE = "fused-pack"
 
@@ -207,12 +207,16 @@ def time_steps(torch, dev, fns, steps, warmup, sync):
 
 
 def secondary_lines(torch, dev, local_rank, T, K, W, H):
-    """The other BASELINE.json configs on this GPU, same process, each checked before it is timed."""
+    """The other BASELINE.json configs on this GPU, same process, each checked before it is timed.  As in the reference's frame
+    loop (V3:556-562) every step brings its own boxes -- cam-0 corners lent in HBM, prepared on the device inside the step."""
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     from oracle import cpu_oracle as orc
+    from oracle import numpy_path as npp
     out = {}
     stream = torch.cuda.Stream(dev)
+    TrVeloToCam = S.default_calibration()[0]
+    Tcv = np.linalg.inv(TrVeloToCam)
 
     def sync():
         stream.synchronize()
@@ -223,26 +227,25 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         ctx.set_camera(T, K, W, H, 0.0, DMAX)
         n = N_POINTS
         scs = [S.scene(n, N_MASKS, N_BOXES, seed=7000 + i) for i in range(6)]     # 6 x 56 MB of traffic: past the 256 MiB cache
-        ctx.set_boxes(scs[0]["corners_velo"])
         bufs = []
         for sc in scs:
             o = make_outputs(torch, dev, n, 1, n, N_MASKS, N_BOXES, SUMMARY_DTYPE.itemsize)
-            bufs.append((torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev), o))
+            bufs.append((torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev), o,
+                         torch.from_numpy(np.ascontiguousarray(sc["corners_cam0"])).to(dev)))
         off = np.array([0, n], np.int64)
-        fns = [ctx.make_device_step(p_, off, masks_u8=m_, inst_cap=n, **o) for p_, m_, o in bufs]
+        boff = np.array([0, N_BOXES], np.int32)
+        fns = [ctx.make_device_step(p_, off, masks_u8=m_, lend=True, boxes_cam0=c_, box_off=boff, T_cam_to_velo=Tcv, inst_cap=n, **o)
+               for p_, m_, o, c_ in bufs]
         sync()
-        fns[0]()
+
+        def check2(what):
+            for i in (0, len(scs) - 1):
+                keep, velo = npp.prepare_boxes(scs[i]["corners_cam0"], K, W, H, TrVeloToCam)
+                check_frames(torch, bufs[i][2], bufs[i][0], [scs[i]], [velo], [keep], n, T, K, W, H, DMAX, what)
+        for f_ in fns:
+            f_()
         sync()
-        o = bufs[0][2]
-        ref = orc.run(scs[0]["points"], T, K, W, H, 0.0, DMAX, label_img=orc.pack_masks(scs[0]["masks"], 0, H, W), M=N_MASKS,
-                      corners=scs[0]["corners_velo"], want_float=False)
-        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
-        ok = (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(o["valid_idx"][:ref["n_valid"]].cpu().numpy(), ref["valid_idx"])
-              and np.array_equal(o["count_mb"].cpu().numpy().reshape(N_MASKS, N_BOXES), ref["count_mb"])
-              and np.array_equal(o["uv"].cpu().numpy(), np.stack([ref["u"], ref["v"]], axis=1))
-              and np.array_equal(o["label_bits"].cpu().numpy().view(np.uint32), ref["label_bits"]))
-        if not ok:
-            raise SystemExit("bench secondary configs[2]: GPU result differs from the CPU oracle")
+        check2("secondary configs[2]")
         dt = time_steps(torch, dev, fns, 300, 30, sync)
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
@@ -250,130 +253,220 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         ms, cnt = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
         k1_us = 1e3 * ms / max(cnt, 1)
-        # the same clouds as a software-pipelined stream (one launch per cloud: its mask pack, the previous cloud's
+        # the same clouds as a software-pipelined stream (one launch per cloud: its mask pack and box set-up, the previous cloud's
         # project+label tiles, the tail of the one before): throughput of a stream of single clouds, not latency
         ctx.set_pipelined("fused-pack")
         for f_ in fns:
             f_()
         ctx.sync()
-        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
-        if not (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(o["count_mb"].cpu().numpy().reshape(N_MASKS, N_BOXES), ref["count_mb"])
-                and np.array_equal(o["valid_idx"][:ref["n_valid"]].cpu().numpy(), ref["valid_idx"])):
-            raise SystemExit("bench secondary configs[2], pipelined stream: GPU result differs from the CPU oracle")
+        check2("secondary configs[2], pipelined stream")
+        ctx.stats(reset=True)
         dt_p = time_steps(torch, dev, fns, 300, 30, lambda: (ctx.sync(), sync()))
+        st = ctx.stats()
         ctx.set_pipelined(False)
         out["configs2_one_2M_cloud_per_launch"] = {
-            "points_per_s": n / dt, "us_per_step": 1e6 * dt, "k1_bracket_us": k1_us,
+            "points_per_s": n / dt, "us_per_step": 1e6 * dt, "k1_bracket_us": k1_us, "boxes_change_every_step": True,
             "k1_algorithmic_GBps": ALGO_BYTES_PER_POINT * n / (k1_us * 1e-6) / 1e9,
             "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * n / dt / 1e9 / HBM_PEAK_GBS,
             "us_per_step_software_pipelined": 1e6 * dt_p, "points_per_s_software_pipelined": n / dt_p,
             "step_algorithmic_frac_of_hbm_peak_software_pipelined": ALGO_BYTES_PER_POINT * n / dt_p / 1e9 / HBM_PEAK_GBS,
-            "checked": "n_valid, valid_idx, u, v, label_bits, count_mb == CPU oracle"}
+            "host_waits_and_drains_in_the_pipelined_stream": [st["host_waits"] - 2, st["drains"] - 2],   # (the two syncs of the timing loop itself)
+            "checked": "first and last cloud: u, v, label_bits, valid_idx, instance lists, count_mb, best box == CPU oracle (in order and pipelined)"}
         del bufs, fns
 
-    # ---- configs[3] shape: the 20 sample frames' worth of REAL scan data in one batch (golden frame 100 x 20) -------
-    gpath = os.path.join(ROOT, "tests", "golden", "frame_0000000100.npz")
+    # ---- real scans: the committed golden frames (reference inputs, reference-generated outputs) -------------------------------
+    gdir = os.path.join(ROOT, "tests", "golden")
+    gpath = os.path.join(gdir, "frame_0000000100.npz")
     if os.path.exists(gpath):
-        g = np.load(gpath)
-        cal = np.load(os.path.join(ROOT, "tests", "golden", "calib_cam0.npz"))
+        cal = np.load(os.path.join(gdir, "calib_cam0.npz"))
         Tg, Kg, Wg, Hg = np.asarray(cal["TrVeloToRect"]), np.asarray(cal["K"])[:3, :3], int(cal["width"]), int(cal["height"])
-        pts = np.ascontiguousarray(g["points"])
-        masks = np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :Wg].astype(np.uint8)
-        corners = g["corners_velo"]
-        n, M, B, F = len(pts), len(masks), len(corners), 20
+        Tcv_g = np.linalg.inv(np.asarray(cal["TrVeloToCam"]))
+
+        def real_frame(path):
+            g = np.load(path)
+            return dict(points=np.ascontiguousarray(g["points"], dtype=np.float32),
+                        masks=np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :Wg].astype(np.uint8),
+                        cam0=np.ascontiguousarray(g["corners_cam0_raw"], dtype=np.float64), pos=g["visible_pos"],
+                        count=g["count_mb_rect5_d50"], n_valid=int(g["valid_idx_d50_len"]) if "valid_idx_d50_len" in g.files else len(g["valid_idx_d50"]),
+                        inst_count=g["inst_count_rect5_d50"])
+
+        def batch_of(frames):
+            """device inputs + outputs of one batch of real frames, and the checker against their golden vectors"""
+            Fb = len(frames)
+            sizes = [len(fr["points"]) for fr in frames]
+            offb = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            nb_ = [len(fr["cam0"]) for fr in frames]
+            boffb = np.concatenate([[0], np.cumsum(nb_)]).astype(np.int32)
+            Mb = frames[0]["masks"].shape[0]
+            d = dict(F=Fb, sizes=sizes, off=offb, boff=boffb, M=Mb, ntot=int(offb[-1]), cap=max(sizes),
+                     pts=torch.from_numpy(np.concatenate([fr["points"] for fr in frames])).to(dev),
+                     masks=torch.from_numpy(np.stack([fr["masks"] for fr in frames])).to(dev),
+                     cam0=torch.from_numpy(np.concatenate([fr["cam0"] for fr in frames])).to(dev))
+            d["o"] = dict(uv=torch.empty((d["ntot"], 2), dtype=torch.int32, device=dev), label_bits=torch.empty(d["ntot"], dtype=torch.int32, device=dev),
+                          valid_idx=torch.empty(d["ntot"], dtype=torch.int64, device=dev),
+                          inst_idx=torch.empty((Fb, d["cap"]), dtype=torch.int64, device=dev),
+                          count_mb=torch.zeros(Mb * int(boffb[-1]), dtype=torch.int32, device=dev),
+                          summary=torch.zeros(Fb * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+
+            def check(what):
+                cm = d["o"]["count_mb"].cpu().numpy()
+                sm = np.frombuffer(d["o"]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+                for f, fr in enumerate(frames):
+                    b0, b1 = int(boffb[f]), int(boffb[f + 1])
+                    c_ = cm[Mb * b0:Mb * b1].reshape(Mb, b1 - b0)
+                    rest = np.ones(b1 - b0, bool)
+                    rest[fr["pos"]] = False
+                    if not (np.array_equal(c_[:, fr["pos"]], fr["count"]) and not c_[:, rest].any() and int(sm[f]["n_valid"]) == fr["n_valid"]
+                            and np.array_equal(sm[f]["inst_count"][:Mb], fr["inst_count"])):
+                        raise SystemExit("bench %s: frame %d differs from the reference-generated golden vectors" % (what, f))
+            d["check"] = check
+            return d
+
+        def stepper(ctx, d):
+            return ctx.make_device_step(d["pts"], d["off"], masks_u8=d["masks"], lend=True, boxes_cam0=d["cam0"], box_off=d["boff"],
+                                        T_cam_to_velo=Tcv_g, filter_visible=True, inst_cap=d["cap"], **d["o"])
+
+        def fused_loop(ctx, fns_, checks, reps):
+            """the same steps in a loop under the software-pipelined mode (a stream of batches: throughput, not latency)"""
+            ctx.set_pipelined("fused-pack")
+            for _ in range(2):
+                for f_ in fns_:
+                    f_()
+            ctx.sync()
+            for c_ in checks:
+                c_()
+            ctx.stats(reset=True)
+            t = time_steps(torch, dev, fns_, reps, 30, lambda: (ctx.sync(), sync()))
+            st_ = ctx.stats()
+            ctx.set_pipelined(False)
+            return t, [st_["host_waits"] - 2, st_["drains"] - 2]
+
+        f100 = real_frame(gpath)
+        n100 = len(f100["points"])
         with torch.cuda.stream(stream), LpfContext(local_rank) as ctx:
             ctx.set_stream(stream.cuda_stream)
             ctx.set_camera(Tg, Kg, Wg, Hg, 0.0, 50.0)
-            ctx.set_boxes([corners] * F)
-            d_pts = torch.from_numpy(np.tile(pts, (F, 1))).to(dev)
-            d_masks = torch.from_numpy(np.tile(masks[None], (F, 1, 1, 1))).to(dev)
-            o = make_outputs(torch, dev, F * n, F, F * n, M, F * B, SUMMARY_DTYPE.itemsize)
-            fn = ctx.make_device_step(d_pts, np.arange(F + 1, dtype=np.int64) * n, masks_u8=d_masks, inst_cap=n, **o)
+            # configs[3] shape: 20 real frames in one batch (frame 100 x 20)
+            d20 = batch_of([f100] * 20)
+            fn20 = stepper(ctx, d20)
             sync()
-            fn()
+            fn20()
             sync()
-            cm = o["count_mb"].cpu().numpy().reshape(F, M, B)
-            sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
-            vi = o["valid_idx"].cpu().numpy()
-            ok = all(np.array_equal(cm[f], g["count_mb_rect5_d50"]) and int(sm[f]["n_valid"]) == len(g["valid_idx_d50"])
-                     and np.array_equal(vi[f * n:f * n + len(g["valid_idx_d50"])], g["valid_idx_d50"]) for f in range(F))
-            if not ok:
-                raise SystemExit("bench secondary configs[3]: GPU result differs from the golden vectors of frame 100")
-            dt = time_steps(torch, dev, [fn], 500, 30, sync)
-
-            def fused_loop(step_fn, check):
-                """the same step in a loop under the software-pipelined mode (a stream of batches: throughput, not latency)"""
-                ctx.set_pipelined("fused-pack")
-                for _ in range(3):
-                    step_fn()
-                ctx.sync()
-                check()
-                t = time_steps(torch, dev, [step_fn], 500, 30, lambda: (ctx.sync(), sync()))
-                ctx.set_pipelined(False)
-                return t
-
-            def check3():
-                cm_ = o["count_mb"].cpu().numpy().reshape(F, M, B)
-                if not all(np.array_equal(cm_[f], g["count_mb_rect5_d50"]) for f in range(F)):
-                    raise SystemExit("bench secondary configs[3], pipelined: GPU result differs from the golden vectors of frame 100")
-            dtf = fused_loop(fn, check3)
+            d20["check"]("secondary configs[3]")
+            dt = time_steps(torch, dev, [fn20], 500, 30, sync)
+            dtf, wd = fused_loop(ctx, [fn20], [lambda: d20["check"]("secondary configs[3], pipelined")], 500)
             out["configs3_20_real_frames_one_batch"] = {
-                "points_per_s": F * n / dt, "us_per_step": 1e6 * dt, "frames": F, "points_per_frame": n, "masks": M, "boxes": B,
-                "us_per_step_software_pipelined": 1e6 * dtf, "points_per_s_software_pipelined": F * n / dtf,
-                "checked": "count_mb, n_valid, valid_idx of every frame == tests/golden/frame_0000000100.npz (reference functions)"}
+                "points_per_s": 20 * n100 / dt, "us_per_step": 1e6 * dt, "frames": 20, "points_per_frame": n100, "masks": d20["M"],
+                "boxes_given_per_frame": len(f100["cam0"]), "boxes_kept_by_filter_visible": len(f100["pos"]), "boxes_change_every_step": True,
+                "us_per_step_software_pipelined": 1e6 * dtf, "points_per_s_software_pipelined": 20 * n100 / dtf,
+                "host_waits_and_drains_in_the_pipelined_stream": wd,
+                "checked": "count_mb (kept boxes; dropped boxes zero), n_valid, inst_count of every frame == tests/golden/frame_0000000100.npz (reference functions)"}
             # ... and the same frame alone (configs[1]): launch-bound
-            o1 = make_outputs(torch, dev, n, 1, n, M, B, SUMMARY_DTYPE.itemsize)
-            ctx.set_boxes(corners)
-            fn1 = ctx.make_device_step(d_pts[:n], np.array([0, n], np.int64), masks_u8=d_masks[:1], inst_cap=n, **o1)
+            d1 = batch_of([f100])
+            fn1 = stepper(ctx, d1)
             fn1()
             sync()
-            if not np.array_equal(o1["count_mb"].cpu().numpy().reshape(M, B), g["count_mb_rect5_d50"]):
-                raise SystemExit("bench secondary configs[1]: GPU result differs from the golden vectors of frame 100")
+            d1["check"]("secondary configs[1]")
             dt1 = time_steps(torch, dev, [fn1], 1000, 30, sync)
-
-            def check1():
-                if not np.array_equal(o1["count_mb"].cpu().numpy().reshape(M, B), g["count_mb_rect5_d50"]):
-                    raise SystemExit("bench secondary configs[1], pipelined: GPU result differs from the golden vectors of frame 100")
-            dt1f = fused_loop(fn1, check1)
-            out["configs1_frame100_device_resident"] = {"points_per_s": n / dt1, "us_per_frame": 1e6 * dt1, "points": n,
+            dt1f, wd1 = fused_loop(ctx, [fn1], [lambda: d1["check"]("secondary configs[1], pipelined")], 1000)
+            out["configs1_frame100_device_resident"] = {"points_per_s": n100 / dt1, "us_per_frame": 1e6 * dt1, "points": n100,
+                                                        "boxes_change_every_frame": True,
                                                         "us_per_frame_in_a_software_pipelined_stream": 1e6 * dt1f,
-                                                        "checked": "count_mb == golden"}
+                                                        "host_waits_and_drains_in_the_pipelined_stream": wd1,
+                                                        "checked": "count_mb, n_valid, inst_count == golden"}
+            del d20, d1, fn20, fn1
+            # ---- real scan order at the headline's size: 146 frames (the four full-size golden frames in turn, 16.9 M points) per
+            #      step, their 5 masks each, their own annotated boxes (31 / 21 / 186 / 314 per frame, filtered on the device), depth < 50
+            full = [f100] + [real_frame(os.path.join(gdir, "frame_%010d_full.npz" % fr)) for fr in (1461, 2098, 2449)
+                             if os.path.exists(os.path.join(gdir, "frame_%010d_full.npz" % fr))]
+            if len(full) == 4:
+                nfr = 146
+                dbs = [batch_of([full[(i + s_) % 4] for i in range(nfr)]) for s_ in range(2)]     # two resident batches (2 x 270 MB of points)
+                fns = [stepper(ctx, d) for d in dbs]
+                sync()
+                for f_ in fns:
+                    f_()
+                sync()
+                for d in dbs:
+                    d["check"]("secondary real scans at headline size")
+                ntot_r = dbs[0]["ntot"]
+                dt_s = time_steps(torch, dev, fns, 60, 6, sync)
+                ctx.set_pipelined("fused-pack")
+                for _ in range(3):
+                    for f_ in fns:
+                        f_()
+                ctx.sync()
+                for d in dbs:
+                    d["check"]("secondary real scans at headline size, pipelined")
+                ctx.stats(reset=True)
+                dt_r = time_steps(torch, dev, fns, 200, 20, lambda: (ctx.sync(), sync()))
+                st = ctx.stats()
+                ctx.profile_enable(True)
+                ctx.profile_read(reset=True)
+                time_steps(torch, dev, fns, 100, 0, lambda: (ctx.sync(), sync()))
+                ms, cnt = ctx.profile_read(reset=True)
+                ctx.profile_enable(False)
+                ctx.set_pipelined(False)
+                sm = np.frombuffer(dbs[0]["o"]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+                nv, nl = int(sm["n_valid"].sum()), int(sm["inst_count"].sum())
+                br = 1e-3 * ms / max(cnt, 1)
+                item = ALGO_BYTES_PER_POINT * ntot_r + 12 * nv + 8 * nl + dbs[0]["M"] * nv      # + label look-ups (M mask bytes per valid point), valid_idx, lists
+                out["real_scans_at_headline_size"] = {
+                    "frames_per_step": nfr, "points_per_step": ntot_r, "valid_fraction": nv / ntot_r, "masked_list_entries_per_step": nl,
+                    "boxes_given_per_step": int(dbs[0]["boff"][-1]), "boxes_change_every_step": True, "mode": "fused-pack",
+                    "us_per_step": 1e6 * dt_r, "points_per_s": ntot_r / dt_r, "us_per_step_in_order": 1e6 * dt_s,
+                    "step_kernel_bracket_us": 1e6 * br,
+                    "strict_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot_r / dt_r / 1e9 / HBM_PEAK_GBS,
+                    "strict_frac_of_hbm_peak_step_kernel": ALGO_BYTES_PER_POINT * ntot_r / br / 1e9 / HBM_PEAK_GBS,
+                    "itemised_bytes_per_step": item, "itemised_frac_of_hbm_peak": item / dt_r / 1e9 / HBM_PEAK_GBS,
+                    "host_waits_and_drains_in_the_pipelined_stream": [st["host_waits"] - 2, st["drains"] - 2],
+                    "data": "KITTI-360 sample frames 100, 1461, 2098, 2449 in turn (tests/golden: the reference's inputs), real scan order",
+                    "checked": "count_mb (kept boxes; dropped boxes zero), n_valid, inst_count of all 146 frames of both batches == the golden vectors (reference functions)"}
+                del dbs, fns
 
-    # ---- configs[4]: stream of 1 M-point frames + 8 masks eroded once, H2D + kernels + D2H in one hipGraph per frame ----
+    # ---- configs[4]: stream of 1 M-point frames + 8 masks eroded once + 32 boxes, H2D + kernels + D2H in one hipGraph per frame ----
     n, M, B = 1_000_000, 8, 32
+    nframes = 600
     scs = [S.scene(n, M, B, seed=1000 + i) for i in range(4)]
     h_pts = torch.empty((n, 4), dtype=torch.float32).pin_memory()
     h_masks = torch.empty((1, M, H, W), dtype=torch.uint8).pin_memory()
+    h_box = torch.empty((B, 8, 3), dtype=torch.float64).pin_memory()
     h_sum = torch.empty(SUMMARY_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
     h_cnt = torch.empty(M * B, dtype=torch.int32).pin_memory()
     with torch.cuda.stream(stream), LpfContext(local_rank) as ctx:
         ctx.set_stream(stream.cuda_stream)
         ctx.set_camera(T, K, W, H, 0.0, 50.0)
-        ctx.set_boxes(scs[0]["corners_velo"])
         d_pts = torch.empty((n, 4), dtype=torch.float32, device=dev)
         d_masks = torch.empty((1, M, H, W), dtype=torch.uint8, device=dev)
+        d_box = torch.empty((B, 8, 3), dtype=torch.float64, device=dev)
         o = make_outputs(torch, dev, n, 1, n, M, B, SUMMARY_DTYPE.itemsize)
         step = ctx.make_device_step(d_pts, np.array([0, n], np.int64), masks_u8=d_masks, erode_iters=1, inst_cap=n, **o)
+        boff = np.array([0, B], np.int32)
 
         def frame_work():
             d_pts.copy_(h_pts, non_blocking=True)
             d_masks.copy_(h_masks, non_blocking=True)
+            d_box.copy_(h_box, non_blocking=True)
+            ctx.set_boxes_device(d_box, boff)               # this frame's boxes (velodyne-frame corners): table set-up inside the graph
             step()
             h_sum.copy_(o["summary"], non_blocking=True)
             h_cnt.copy_(o["count_mb"], non_blocking=True)
 
-        h_pts.copy_(torch.from_numpy(scs[0]["points"]))
-        h_masks.copy_(torch.from_numpy(scs[0]["masks"])[None])
+        def load(sc):
+            h_pts.copy_(torch.from_numpy(sc["points"]))
+            h_masks.copy_(torch.from_numpy(sc["masks"])[None])
+            h_box.copy_(torch.from_numpy(np.ascontiguousarray(sc["corners_velo"])))
+
+        load(scs[0])
         frame_work()
         ctx.sync()
         ctx.graph_begin()
         frame_work()
         gr = ctx.graph_end()
         lat = []
-        for i in range(104):
+        for i in range(nframes + 4):
             sc = scs[i % len(scs)]
-            h_pts.copy_(torch.from_numpy(sc["points"]))
-            h_masks.copy_(torch.from_numpy(sc["masks"])[None])
+            load(sc)
             time.sleep(0.002)                                # a sensor does not deliver frames back to back
             t0 = time.perf_counter()
             ctx.graph_launch(gr)
@@ -382,18 +475,61 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             if i < len(scs):
                 sm = np.frombuffer(h_sum.numpy().tobytes(), SUMMARY_DTYPE)[0]
                 ref = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=orc.pack_masks(sc["masks"], 1, H, W), M=M,
-                              corners=scs[0]["corners_velo"], want_float=False)
+                              corners=sc["corners_velo"], want_float=False)
                 if not (int(sm["n_valid"]) == ref["n_valid"] and np.array_equal(sm["inst_count"][:M], ref["inst_count"])
                         and np.array_equal(h_cnt.numpy().reshape(M, B), ref["count_mb"]) and np.array_equal(sm["best_box"][:M], ref["best_box"])):
                     raise SystemExit("bench secondary configs[4]: GPU result differs from the CPU oracle")
         ctx.graph_destroy(gr)
         lat = 1e3 * np.array(lat[4:])
         out["configs4_stream_hipgraph_per_frame"] = {
-            "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "max_ms": float(lat.max()),
-            "frames": int(len(lat)), "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "budget_ms_at_10Hz": 100.0,
-            "includes": "H2D of points + masks (pinned), mask pack + erosion, project+label, lists + box counts, finalize, D2H of counts + summary",
+            "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "p99_ms": float(np.percentile(lat, 99)),
+            "max_ms": float(lat.max()),
+            "frames": int(len(lat)), "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "boxes_change_every_frame": True,
+            "budget_ms_at_10Hz": 100.0,
+            "includes": "H2D of points + masks + box corners (pinned), box table set-up, mask pack + erosion, project+label, lists + box counts, "
+                        "finalize, D2H of counts + summary",
             "checked": "n_valid, inst_count, count_mb, best_box of the first 4 frames == CPU oracle"}
     return out
+
+
+def check_frames(torch, out, pts_dev_b, scenes, velo_per_frame, keep_per_frame, n, T, K, W, H, dmax, what):
+    """Every frame of one finished step against the CPU oracle: pixels, labels, valid_idx, every instance list, box counts
+    (a box that filter_visible_bboxes dropped: a zero column), best boxes, summary.  Raises SystemExit on the first difference."""
+    from lidar_object_detection_amd._native import SUMMARY_DTYPE
+    from oracle import cpu_oracle as orc
+    F = len(scenes)
+    M = N_MASKS
+    sm = np.frombuffer(out["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+    boff = 0
+    tot = dict(n_valid=0, n_masked=0, n_list=0)
+    for f in range(F):
+        pts_h = pts_dev_b[f * n:(f + 1) * n].cpu().numpy()
+        keep, velo = keep_per_frame[f], velo_per_frame[f]
+        B = len(keep)
+        lab = orc.pack_masks(scenes[f]["masks"], 0, H, W)
+        o = orc.run(pts_h, T, K, W, H, 0.0, dmax, label_img=lab, M=M, corners=velo[keep], want_float=False)
+        a = f * n
+        uv = out["uv"][a:a + n].cpu().numpy()
+        cm = out["count_mb"][M * boff:M * (boff + B)].cpu().numpy().reshape(M, B)
+        pos = np.flatnonzero(keep)
+        want_best = np.where(o["best_box"] >= 0, pos[np.maximum(o["best_box"], 0)] if len(pos) else -1, -1)
+        ok = (int(sm[f]["n_valid"]) == o["n_valid"] and np.array_equal(sm[f]["inst_count"][:M], o["inst_count"])
+              and np.array_equal(uv[:, 0], o["u"]) and np.array_equal(uv[:, 1], o["v"])
+              and np.array_equal(out["label_bits"][a:a + n].cpu().numpy().view(np.uint32), o["label_bits"])
+              and np.array_equal(out["valid_idx"][a:a + o["n_valid"]].cpu().numpy(), o["valid_idx"])
+              and np.array_equal(cm[:, keep], o["count_mb"]) and not cm[:, ~keep].any()
+              and np.array_equal(sm[f]["best_box"][:M], want_best) and np.array_equal(sm[f]["best_cnt"][:M], o["best_cnt"])
+              and int(sm[f]["n_labelled"]) == int(np.count_nonzero(o["label_bits"])))
+        if ok:
+            inst = out["inst_idx"][f * n:(f + 1) * n].cpu().numpy()          # inst_cap = n entries per frame
+            for m in range(M):
+                lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+                ok = ok and np.array_equal(inst[lo:hi], o["inst_lists"][m])
+        if not ok:
+            raise SystemExit("bench (%s): frame %d of the checked step differs from the CPU oracle -- refusing to report a number" % (what, f))
+        tot["n_valid"] += o["n_valid"]; tot["n_masked"] += int(np.count_nonzero(o["label_bits"])); tot["n_list"] += int(o["inst_count"].sum())
+        boff += B
+    return tot
 
 
 def main():
@@ -404,14 +540,10 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per cloud")
     ap.add_argument("--frames", type=int, default=8, help="clouds per step (one batched launch)")
     ap.add_argument("--buffers", type=int, default=4, help="distinct resident batches cycled through")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams (one context each) the steps alternate over; 2 overlaps the short kernels of one "
-                         "step with the streaming kernel of the next (higher points/s, longer per-kernel durations)")
     ap.add_argument("--mode", default=DEFAULT_MODE, choices=sorted(MODES),
-                    help="how a step's kernels are queued: " + "; ".join("%s = %s" % (k, v[3]) for k, v in sorted(MODES.items())))
-    ap.add_argument("--pipeline", action="store_true", help="same as --mode pipeline")
-    ap.add_argument("--side-cus", type=int, default=-1, help="override the mode's CU partition (multiple of 8, 0 = none)")
-    ap.add_argument("--exclusive", action="store_true", help="with a CU partition: the main stream runs on the other CUs only")
+                    help="how a step's kernels are queued: " + "; ".join("%s = %s" % (k, v[1]) for k, v in sorted(MODES.items())))
+    ap.add_argument("--static-boxes", action="store_true", help="set the boxes once instead of with every step (the reference's loop "
+                                                                "builds a new box list per frame: V3:556-562)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path without RCCL")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -421,8 +553,6 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command of --gpus N and exit (tests)")
     ap.add_argument("--lab", default="", help="diagnosis only (no oracle check, never a reported number): 'nolists', 'noboxes' or 'nomasks'")
     args = ap.parse_args()
-    if args.pipeline:
-        args.mode = "pipeline"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:], dry=args.dry_launch)
@@ -451,17 +581,21 @@ def main():
 
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    from oracle import numpy_path as npp
 
-    _, T, K, W, H = S.default_calibration()
+    TrVeloToCam, T, K, W, H = S.default_calibration()
+    Tcv = np.linalg.inv(TrVeloToCam)
     n, F = args.points, args.frames
     nbuf = max(1, args.buffers)
     ntot = n * F
+    per_step_boxes = not args.static_boxes and args.lab not in ("noboxes", "nowork")
     # F distinct seeded clouds per rank (rank r, frame f -> seed 1000*r + f); the further resident
-    # batches are GPU-side permutations of them (distinct addresses, same statistics)
+    # batches are GPU-side permutations of them (distinct addresses, same statistics).  Boxes: every resident batch has its
+    # own (seeded) 3D boxes, given as the annotation gives them -- 8 corners in the cam-0 frame.
     scenes = [S.scene(n, N_MASKS, N_BOXES, seed=1000 * rank + f) for f in range(F)]
     base_pts = torch.from_numpy(np.concatenate([sc["points"] for sc in scenes], axis=0)).to(dev)
     masks0 = torch.from_numpy(np.stack([sc["masks"] for sc in scenes])).to(dev)           # [F,8,H,W] u8
-    pts_dev, masks_dev, outs = [], [], []
+    pts_dev, masks_dev, outs, cam0_host, cam0_dev, velo_ref, keep_ref = [], [], [], [], [], [], []
     for b in range(nbuf):
         if b == 0:
             pts_dev.append(base_pts)
@@ -471,7 +605,14 @@ def main():
             del perm
         masks_dev.append(masks0.clone() if b else masks0)
         outs.append(make_outputs(torch, dev, ntot, F, ntot, N_MASKS, F * N_BOXES, SUMMARY_DTYPE.itemsize))
+        bb = b if per_step_boxes else 0
+        cam = [scenes[f]["corners_cam0"] if bb == 0 else S.synthetic_boxes(N_BOXES, seed=500_000 * bb + 1000 * rank + f)[0] for f in range(F)]
+        cam0_host.append(cam)
+        cam0_dev.append(torch.from_numpy(np.ascontiguousarray(np.concatenate(cam).reshape(-1, 8, 3))).to(dev))
+        prep = [npp.prepare_boxes(c, K, W, H, TrVeloToCam) for c in cam]                   # the reference's own box preparation (restated)
+        keep_ref.append([p_[0] for p_ in prep]); velo_ref.append([p_[1] for p_ in prep])
     frame_off = np.arange(F + 1, dtype=np.int64) * n
+    box_off = np.arange(F + 1, dtype=np.int32) * N_BOXES
 
     def barrier():
         if world > 1:
@@ -479,43 +620,36 @@ def main():
 
     def measure(mode, steps, warmup, events):
         """`steps` timed steps under queueing mode `mode` (+ a second, event-bracketed pass), checked against the oracle."""
-        # Contexts run on streams of their own (a CU partition needs that).  Everything above was queued on torch's
-        # current stream, and the caching allocator may have carved the output tensors from memory that kernels still
-        # queued there read (the index tensors of the gathers): each context gets an explicit device-side edge behind
-        # that stream before its first kernel, instead of relying on a device-wide synchronisation (DESIGN.md, "The
-        # bench_s1 fault").
-        pipelined, pack_side, side_cus, _ = MODES[mode]
-        if args.side_cus >= 0:
-            side_cus = args.side_cus
-        nstream = max(1, min(args.streams, nbuf))
-        nb = nbuf - nbuf % nstream                          # buffer b always belongs to context b % nstream
-        ctxs = []
-        for _ in range(nstream):
-            c = LpfContext(local_rank)
-            if side_cus:
-                c.set_cu_partition(side_cus, exclusive=args.exclusive)
-            c.set_pipelined(pipelined, pack_side=pack_side)
-            c.set_camera(T, K, W, H, 0.0, DMAX)
-            if args.lab not in ("noboxes", "nowork"):
-                c.set_boxes([sc["corners_velo"] for sc in scenes], oriented=True)   # box tables resident in HBM
-            c.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
-            ctxs.append(c)
-        # one step = K8 mask pack (u8 masks in HBM -> label images) + project/label + lists + box counts + summaries, pre-marshalled
-        steps_fn = [ctxs[b % nstream].make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b],
-                                                       inst_cap=n, **outs[b])
+        # The context runs on a stream of its own.  Everything above was queued on torch's current stream, and the caching
+        # allocator may have carved the output tensors from memory that kernels still queued there read (the index tensors
+        # of the gathers): the context gets an explicit device-side edge behind that stream before its first kernel, instead
+        # of relying on a device-wide synchronisation (DESIGN.md, "The bench_s1 fault").
+        ctx = LpfContext(local_rank)
+        ctx.set_pipelined(MODES[mode][0])
+        ctx.set_camera(T, K, W, H, 0.0, DMAX)
+        if not per_step_boxes and args.lab not in ("noboxes", "nowork"):
+            ctx.set_boxes_cam0(cam0_host[0], Tcv, filter_visible=True, want_outputs=False)     # box tables resident in HBM
+        ctx.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)
+        # one step = box preparation + table set-up (lent cam-0 corners in HBM) + K8 mask pack (lent u8 masks in HBM -> label images)
+        # + project/label + lists + box counts + summaries, pre-marshalled
+        nb = nbuf
+        steps_fn = [ctx.make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b], lend=True,
+                                         boxes_cam0=cam0_dev[b] if per_step_boxes else None, box_off=box_off, T_cam_to_velo=Tcv,
+                                         filter_visible=True, inst_cap=n, **outs[b])
                     for b in range(nb)]
 
         def drain():                                        # pipelined modes: launch what the last runs still owe, then wait
-            for c in ctxs:
-                c.sync()
+            ctx.sync()
             torch.cuda.synchronize(dev)
 
         def timed(k):
             barrier()
             drain()
+            ctx.stats(reset=True)
             t0 = time.perf_counter()
             for i in range(k):
                 steps_fn[i % nb]()
+            queued = ctx.stats()                            # what the host did while it queued the k steps
             drain()                                         # inside the timed region: nothing of the k steps is left undone
             if world > 1:                                   # final aggregate metrics only
                 sm = np.frombuffer(outs[(k - 1) % nb]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
@@ -528,45 +662,31 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
+            return float(t.item()), queued
 
         for i in range(warmup):
             steps_fn[i % nb]()
         drain()
-        res = {"mode": mode, "steps": steps, "nbuf": nb, "nstream": nstream, "pipelined": bool(pipelined), "pack_side": bool(pack_side),
-               "side_cus": side_cus, "elapsed": timed(steps), "k1_ms": 0.0, "k1_n": 0, "elapsed_ev": None, "empty_ms": 0.0}
+        el, queued = timed(steps)
+        res = {"mode": mode, "steps": steps, "nbuf": nb, "elapsed": el, "queued": queued, "k1_ms": 0.0, "k1_n": 0, "elapsed_ev": None, "empty_ms": 0.0}
         if events:                                          # pass 2: same steps, HIP events around the dominant kernel
-            res["empty_ms"] = float(np.median([c.profile_overhead() for c in ctxs]))   # what an empty bracket measures, live
-            for c in ctxs:
-                c.profile_enable(True)
-                c.profile_read(reset=True)
-            res["elapsed_ev"] = timed(steps)
-            for c in ctxs:
-                ms_c, n_c = c.profile_read(reset=True)
-                res["k1_ms"], res["k1_n"] = res["k1_ms"] + ms_c, res["k1_n"] + n_c
-                c.profile_enable(False)
-        # the numbers are only reported if the last step's results equal the CPU oracle's (frame 0, rank 0)
+            res["empty_ms"] = float(ctx.profile_overhead())           # what an empty bracket measures, live
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            res["elapsed_ev"] = timed(steps)[0]
+            res["k1_ms"], res["k1_n"] = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+        # the numbers are only reported if EVERY frame of the last step equals the CPU oracle's results (rank 0), instance
+        # lists included -- and, with per-step boxes, also the step before it (another batch, other boxes)
         if rank == 0 and not args.lab:
-            from oracle import cpu_oracle as orc
-            b = (steps - 1) % nb
-            sm = np.frombuffer(outs[b]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
-            pts_h = pts_dev[b][:n].cpu().numpy()
-            lab = orc.pack_masks(scenes[0]["masks"], 0, H, W)
-            o = orc.run(pts_h, T, K, W, H, 0.0, DMAX, label_img=lab, M=N_MASKS, corners=scenes[0]["corners_velo"],
-                        want_float=False)
-            ok = (int(sm[0]["n_valid"]) == o["n_valid"] and np.array_equal(sm[0]["inst_count"][:N_MASKS], o["inst_count"])
-                  and np.array_equal(outs[b]["count_mb"][:N_MASKS * N_BOXES].cpu().numpy().reshape(N_MASKS, N_BOXES), o["count_mb"])
-                  and np.array_equal(outs[b]["valid_idx"][:o["n_valid"]].cpu().numpy(), o["valid_idx"])
-                  and np.array_equal(outs[b]["uv"][:n].cpu().numpy(), np.stack([o["u"], o["v"]], axis=1))
-                  and np.array_equal(outs[b]["label_bits"][:n].cpu().numpy().view(np.uint32), o["label_bits"])
-                  and np.array_equal(sm[0]["best_box"][:N_MASKS], o["best_box"]))
-            if not ok:
-                raise SystemExit("bench (%s): GPU result differs from the CPU oracle -- refusing to report a number" % mode)
-            res["n_valid_batch"] = int(sm["n_valid"].sum())
-            res["n_masked_batch"] = int(sm["n_labelled"].sum())
-            res["n_list_entries_batch"] = int(sm["inst_count"].sum())
-        for c in ctxs:
-            c.close()
+            for back in ((0, 1) if (per_step_boxes and steps > 1 and nb > 1) else (0,)):
+                b = (steps - 1 - back) % nb
+                tot = check_frames(torch, outs[b], pts_dev[b], scenes, velo_ref[b], keep_ref[b], n, T, K, W, H, DMAX, mode)
+                if back == 0:
+                    res["n_valid_batch"], res["n_masked_batch"], res["n_list_entries_batch"] = tot["n_valid"], tot["n_masked"], tot["n_list"]
+            res["checked"] = "every frame of the last step%s: u, v, label_bits, valid_idx, every instance list, count_mb, best box, summary == CPU oracle" % (
+                " and of the one before it (other boxes)" if per_step_boxes and steps > 1 and nb > 1 else "")
+        ctx.close()
         return res
 
     if args.lab in ("nolists", "nowork"):
@@ -579,8 +699,8 @@ def main():
     if world == 1 and not args.no_secondary and args.mode != "serial" and not args.lab:
         serial_run = measure("serial", min(args.steps, 100), min(args.warmup, 10), True)
     elapsed, k1_ms, k1_n, elapsed_ev, empty_ms = (main_run[k] for k in ("elapsed", "k1_ms", "k1_n", "elapsed_ev", "empty_ms"))
-    nbuf, nstream, pipelined, pack_side, side_cus = (main_run[k] for k in ("nbuf", "nstream", "pipelined", "pack_side", "side_cus"))
-    del pts_dev, masks_dev, outs, base_pts, masks0
+    nbuf = main_run["nbuf"]
+    del pts_dev, masks_dev, outs, base_pts, masks0, cam0_dev
 
     if rank == 0:
         total_points = float(ntot) * args.steps * world
@@ -598,13 +718,17 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2] shape, batched: %d synthetic clouds x %d points per step, each with %d disk "
-                                   "masks + %d 3D boxes, V4 clip depth<30; one launch set per step produces all outputs "
-                                   "(u,v,label,valid_idx,instance lists,count_mb,best box)" % (F, n, N_MASKS, N_BOXES),
+                                   "masks + %d 3D boxes, V4 clip depth<30; %s; one launch set per step produces all outputs "
+                                   "(u,v,label,valid_idx,instance lists,count_mb,best box)"
+                                   % (F, n, N_MASKS, N_BOXES, "every step brings its own boxes (cam-0 corners: filter_visible_bboxes + "
+                                      "transform_bboxes_to_velodyne + table set-up on the device, inside the step)" if per_step_boxes
+                                      else "boxes set once"),
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
-                       "masks": N_MASKS, "boxes": N_BOXES, "resident_batches_per_gpu": nbuf, "hip_streams": nstream,
-                       "mode": args.mode, "tail_kernels_overlap_next_step": bool(pipelined), "mask_pack_on_side_stream": bool(pack_side),
-                       "side_stream_cus": side_cus, "main_stream_excludes_them": bool(args.exclusive and side_cus),
+                       "masks": N_MASKS, "boxes": N_BOXES, "boxes_change_every_step": bool(per_step_boxes),
+                       "masks_change_every_step": True, "resident_batches_per_gpu": nbuf, "mode": args.mode,
+                       "host_while_queueing_the_timed_steps": main_run["queued"],
                        "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                       "checked": main_run.get("checked"),
                        "sharding": "clouds per rank, no data-path collective"},
         }
         if k1_n:
@@ -625,9 +749,9 @@ def main():
                     itemised += F * (N_MASKS + 1) * W * H
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                                "kernel": "lpf_step_t (mask pack of this step + project+label tiles of the previous one + tail blocks of the one before)"
+                                "kernel": "lpf_step_t (mask pack + box set-up of this step + project+label tiles of the previous one + tail blocks of the one before)"
                                 if args.mode == "fused-pack" else
-                                "lpf_step_t (project+label tiles of this step + tail blocks of the previous one)" if args.mode == "fused"
+                                "lpf_step_t (project+label tiles + box set-up of this step + tail blocks of the previous one)" if args.mode == "fused"
                                 else "lpf_k1_project_t", "avg_us": 1e6 * dur_s, "launches": k1_n,
                                 "empty_bracket_us": 1e3 * empty_ms,
                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * ntot,
@@ -642,7 +766,7 @@ def main():
         if args.lab:
             line["metric"] = "LAB RUN (%s): not a benchmark result" % args.lab
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(scenes[0], T, K, W, H, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(dict(scenes[0], corners_velo=velo_ref[0][0][keep_ref[0][0]]), T, K, W, H, args.cpu_seconds)
         if world == 1 and not args.no_secondary:
             line["secondary"] = secondary_lines(torch, dev, local_rank, T, K, W, H)
             if serial_run is not None:
@@ -652,7 +776,8 @@ def main():
                     "points_per_s": float(ntot) * serial_run["steps"] / serial_run["elapsed"],
                     "k1_bracket_us": 1e6 * sd, "k1_algorithmic_GBps": ALGO_BYTES_PER_POINT * ntot / sd / 1e9,
                     "k1_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / sd / 1e9 / HBM_PEAK_GBS,
-                    "note": "every kernel of a step on one stream, in order (pack, project+label, lists + box counts, summaries): the "
+                    "boxes_change_every_step": bool(per_step_boxes),
+                    "note": "every kernel of a step on one stream, in order (box job, pack, project+label, lists + box counts, summaries): the "
                             "project+label kernel runs alone on the chip here"}
         print(json.dumps(line), flush=True)
     if world > 1:

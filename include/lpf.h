@@ -32,10 +32,15 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 4          /* 2: lpf_outputs gained uv_valid / label_valid
+#define LPF_ABI_VERSION 5          /* 2: lpf_outputs gained uv_valid / label_valid
                                       3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
-                                         lpf_set_pipelined modes; lpf_set_cu_partition; stale graphs are refused
-                                      4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4); lpf_set_geometry */
+                                         lpf_set_pipelined modes; stale graphs are refused
+                                      4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4)
+                                      5: boxes per run in the software-pipelined modes (a ring of box sets, their preparation rides in
+                                         the run's launch; on_device = 2 = lent corners in lpf_set_boxes_ex / lpf_set_boxes_cam0);
+                                         geometry tables per run (a new batch shape no longer drains the pipeline);
+                                         lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
+                                         section 8); lpf_set_geometry only in lab builds (-DLPF_LAB) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -101,47 +106,44 @@ int  lpf_use_own_stream(lpf_ctx *ctx);
  * caller's stream (lpf_set_stream) is ordered with the caller's work by the stream itself.  A context on its own
  * stream is NOT: inputs produced on another stream, and -- with a stream-ordered caching allocator such as torch's
  * -- even output buffers, whose memory may still be in use by kernels queued earlier on the allocating stream, need an
- * edge first.  lpf_wait_for_stream makes the context's stream(s) wait, on the device, for everything queued so far
- * on producer; lpf_release_to_stream makes consumer wait for everything the context has queued (tail and pack
- * streams of the pipelined mode included).  Neither blocks the host.  (A missing edge is how round 1's bench once
+ * edge first.  lpf_wait_for_stream makes the context's stream wait, on the device, for everything queued so far
+ * on producer; lpf_release_to_stream makes consumer wait for everything the context has queued (what the pipelined
+ * modes still owe is launched first).  Neither blocks the host.  (A missing edge is how round 1's bench once
  * died inside torch's set-up gather: DESIGN.md, "The bench_s1 fault".) */
 int  lpf_wait_for_stream(lpf_ctx *ctx, void *producer_stream);
 int  lpf_release_to_stream(lpf_ctx *ctx, void *consumer_stream);
 int  lpf_sync(lpf_ctx *ctx);
-/* Pipelined device-mode runs.  on = 2 (the fast one): software pipelining inside ONE launch per run -- the launch
- * of run i carries its own streaming kernel, the tail (index lists, box counts) of run i-1 dealt out among the
- * streaming tiles, and the per-frame summaries of run i-2; three scratch sets rotate, nothing in a launch depends on
- * anything else in it, no second stream and no event is involved.  What is still owed is launched by lpf_sync(),
- * lpf_release_to_stream() or any call that changes the context's state.
+/* Software-pipelined device-mode runs.  on = 2: ONE launch per run -- the launch of run i carries its own streaming
+ * kernel, the tail (index lists, box counts) of run i-1 dealt out among the streaming tiles, and the per-frame summaries of
+ * run i-2; three scratch sets rotate, nothing in a launch depends on anything else in it, no second stream and no event is
+ * involved.  What is still owed is launched by lpf_sync(), lpf_release_to_stream() or a call that needs the pipeline empty.
  * on = 4: as 2, and the MASK PACK rides as well, so that nothing is left on the stream between two launches: the launch
  * made by run i carries the pack of run i's masks (uint8 masks lent with on_device = 2 and no erosion; other masks are
  * packed by their own launch as before), the streaming kernel of run i-1 -- its label images were packed one launch
  * earlier -- the tail of run i-2 and the summaries of run i-3; the pack blocks come behind the streaming tiles and fill
  * their ramp-down (16 M-point step: 92 us instead of 98).  Four scratch sets rotate.  A run's POINTS are read, and its
  * outputs written, by the launch of the NEXT run (or by lpf_sync / lpf_release_to_stream): keep them untouched until then.
- * on = 1: the short tail kernels of a run (index lists, box counts,
- * per-frame summary) execute on a second, internal stream and overlap the streaming kernel of
- * the next run, which uses a second set of scratch buffers.  on = 3: in addition device-mode
- * lpf_set_masks_* pack on a third internal stream, into the label images of the NEXT run, so the pack overlaps
- * the streaming kernel already queued; the mask tensor must then be complete when lpf_set_masks_* is
- * called (the side stream does not wait for the caller's stream).  With any of them on, the outputs of a run are
- * complete after lpf_sync() (or lpf_release_to_stream()), not after the caller's stream alone, and the caller's
- * output buffers of a run must stay untouched until then.  The label images rotate with the scratch sets: call
- * lpf_set_masks_* before every lpf_run* while a pipelined mode is on.  0 = off (default). */
+ * Per-run state travels with the run: the label images rotate with the scratch sets (call lpf_set_masks_* before every
+ * lpf_run* while a pipelined mode is on); lpf_set_boxes* for the next run writes the next of four box sets and its table
+ * set-up rides in that run's launch (boxes that are not set again stay in force); a run whose batch shape differs from the
+ * previous one's brings its own frame / segment / block tables -- none of these drains the pipeline or waits for the GPU.
+ * Lent inputs (on_device = 2: masks, box corners) of run i must stay unchanged until the launch after the next has been
+ * queued AND has executed, i.e. until the results of run i are complete.  With a pipelined mode on, the outputs of a run are
+ * complete after lpf_sync() (or lpf_release_to_stream()), not after the caller's stream alone.  0 = off (default).
+ * (Modes 1 and 3 -- tail kernels / mask pack on internal side streams -- and lpf_set_cu_partition existed up to ABI 4; they
+ *  measured slower than mode 2 on every workload and were removed.) */
 int  lpf_set_pipelined(lpf_ctx *ctx, int on);
-/* Confine the internal side streams of the pipelined mode to side_cus compute units (a multiple of 8: the same
- * share of each of the 8 XCDs; 0 = no confinement), so the tail kernels do not take issue slots from the
- * streaming kernel everywhere.  exclusive = 1 additionally confines the context's OWN main stream to the
- * remaining CUs (not possible on a caller's stream).  Call before lpf_set_pipelined or at any idle point. */
-int  lpf_set_cu_partition(lpf_ctx *ctx, int side_cus, int exclusive);
 
-/* Launch geometry.  A run cuts every frame into segments -- one list wave each -- and K1 tiles: 1024-point segments of
- * 512-point tiles for launches of up to 3.5 Mi points (a real frame is then ~107 waves instead of 27), 4096-point
- * segments of 1024-point tiles beyond; a launch of a few frames runs the tail in its wide form (16 waves share the masked
- * points of four segments).  Results do not depend on any of it.  0 = by launch size (default), 1 = small with the wide
- * tail, 2 = large, 3 = large with the segment prefixes taken from the scan kernel (what frames of more than 64 x 64
- * segments get by themselves), 4 = small with the narrow tail.  For tests and tuning. */
+#ifdef LPF_LAB
+/* Lab builds only (liblpf_lab.so; tools/ and the forced-geometry tests).  Launch geometry: a run cuts every frame into
+ * segments -- one list wave each -- and K1 tiles: 1024-point segments of 512-point tiles for launches of up to 3.5 Mi points
+ * (a real frame is then ~107 waves instead of 27), 4096-point segments of 1024-point tiles beyond; a launch of a few frames
+ * runs the tail in its wide form (16 waves share the masked points of four segments).  Results do not depend on any of it.
+ * 0 = by launch size (what the product always does), 1 = small with the wide tail, 2 = large, 3 = large with the segment
+ * prefixes taken from the scan kernel (what frames of more than 64 x 64 segments get by themselves), 4 = small with the
+ * narrow tail. */
 int  lpf_set_geometry(lpf_ctx *ctx, int mode);
+#endif
 
 /* ---- per-sequence state --------------------------------------------------------
  * Replaces V3:565-569 + V3:584 constants.  T = TrVeloToRect (row-major 4x4, V3:535),
@@ -180,22 +182,26 @@ int lpf_get_label_image(lpf_ctx *ctx, uint32_t *out, int on_device);
  * (output of transform_bboxes_to_velodyne, V3:41-52); frame f owns boxes
  * [box_off[f], box_off[f+1]).  oriented = 1: oriented_point_in_bbox (V3:167-204, the
  * three skewed slabs c1-c0, c3-c0, c4-c0); 0: point_in_bbox (V3:143-164).  box_off: host memory.
- * The box tables (slab parameters in the reference's arithmetic, float bounds, per-cell candidate lists) are built
- * by one kernel on the context's stream: no host work, and -- as long as the box COUNTS are those of the previous
- * call -- no synchronisation, so a per-frame box change can sit inside a captured graph (lpf_set_boxes_ex with
- * on_device = 1: the corners are read from the caller's device buffer when the graph runs).
+ * The box tables (slab parameters in the reference's arithmetic, float bounds, per-cell candidate lists) are built on the
+ * device by one block per frame -- a kernel on the context's stream in serial mode (capturable: with unchanged box counts a
+ * per-frame box change sits inside a captured graph), blocks of the next lpf_run*'s own launch in the software-pipelined
+ * modes.  No call waits for the GPU unless it returns results to host memory or has to grow a buffer.
+ * on_device: 0 = host memory (copied before the call returns); 1 = device memory, copied in stream order by this call (the
+ * buffer may be rewritten, in stream order, as soon as the call has returned); 2 = device memory LENT to the context: read
+ * when the tables are built (by the next lpf_run* in the pipelined modes), it stays unchanged until that run has completed.
  * lpf_set_camera must come first; changing W or H afterwards drops the boxes. */
 int lpf_set_boxes(lpf_ctx *ctx, const double *corners_velo, const int32_t *box_off, int F, int oriented);
 int lpf_set_boxes_ex(lpf_ctx *ctx, const double *corners_velo, int on_device, const int32_t *box_off, int F, int oriented);
 /* The reference's per-frame box preparation and lpf_set_boxes in one device-side step (V3:556-562):
- *   corners_cam0  f64 [Btot][8][3], the 'corners_cam0' of BBoxes_<frame>.json (host or device per on_device)
+ *   corners_cam0  f64 [Btot][8][3], the 'corners_cam0' of BBoxes_<frame>.json (host or device per on_device, as above)
  *   T_cam_to_velo inv(TrVeloToCam), row-major 4x4 (host)
  *   filter_visible = 1: boxes that filter_visible_bboxes (V3:121-140) drops stay in the tables at their position but can
  *                  never be hit: count_mb keeps one column per GIVEN box (zero for a dropped one) and best_box indexes the
  *                  given list; the position in the reference's filtered list is the number of kept boxes before it.
  * Optional outputs (NULL = not wanted; host or device like the input): visible[Btot] (1 = kept), corners_velo
- * [Btot][8][3] (transform_bboxes_to_velodyne, V3:41-52), bbox2d [Btot][4] and front [Btot] as lpf_prepare_boxes.
- * Device mode neither copies through the host nor synchronises (capturable under the rule above). */
+ * [Btot][8][3] (transform_bboxes_to_velodyne, V3:41-52), bbox2d [Btot][4] and front [Btot] as lpf_prepare_boxes.  Host outputs
+ * are filled when the call returns (it waits for them); device outputs are written when the tables are built -- in the
+ * pipelined modes by the launch of the next lpf_run*, or by lpf_sync / lpf_release_to_stream if that comes first. */
 int lpf_set_boxes_cam0(lpf_ctx *ctx, const double *corners_cam0, int on_device, const int32_t *box_off, int F,
                        const double T_cam_to_velo[16], int filter_visible, int oriented,
                        uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front);
@@ -245,8 +251,8 @@ int lpf_prepare_boxes(lpf_ctx *ctx, const double *corners_cam0, int nbox, const 
  * have run the same shapes once before capture (so no allocation or table upload happens inside
  * it), and pipelining must be off.  For launch-bound per-frame loops (10 Hz streaming).
  * A graph points into buffers and tables the context owns.  Anything that moves or rewrites them after the
- * capture -- a run with another batch geometry, lpf_set_boxes, lpf_set_camera, lpf_set_stream, a mode switch, a
- * call that had to grow a scratch buffer -- makes the graph stale: lpf_graph_launch then returns LPF_ERR_STATE
+ * capture -- a run with another batch geometry, lpf_set_boxes with other box counts, lpf_set_camera, lpf_set_stream, a mode
+ * switch, a call that had to grow a scratch buffer -- makes the graph stale: lpf_graph_launch then returns LPF_ERR_STATE
  * instead of replaying it.  An error returned by a call made inside a capture abandons the capture. */
 typedef struct lpf_graph lpf_graph;
 int  lpf_graph_begin(lpf_ctx *ctx);
@@ -264,6 +270,12 @@ int lpf_profile_read(lpf_ctx *ctx, double *k1_ms_sum, int64_t *k1_launches, int 
 /* Duration between two event records with nothing between them on the context's stream (median of 33):
  * the part of an lpf_profile_* bracket that is not the kernel (4.6 us on MI355X / ROCm 7.2). */
 int lpf_profile_overhead(lpf_ctx *ctx, double *empty_bracket_ms);
+
+/* What the context has done so far (for tests and tuning: a software-pipelined stream must show no host wait and no drain):
+ * out[0] host waits (the calling thread blocked on the GPU), [1] drains (owed work of the pipelined modes launched outside
+ * a run), [2] table / corner uploads through the pinned ring (no wait), [3] step launches, [4] box jobs launched as a kernel
+ * of their own, [5] box jobs that rode in a step launch, [6] uploads too large for the ring (they wait); n <= 8. */
+int lpf_get_stats(lpf_ctx *ctx, int64_t *out, int n, int reset);
 
 /* ---- multi-GPU: the one exchange step ------------------------------------------------------------
  * Frames shard across ranks with no data-path collective (V3:541: the frame loop has no cross-frame state);

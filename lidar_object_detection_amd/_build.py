@@ -10,6 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liblpf.so")
+LAB_LIB = os.path.join(_HERE, "liblpf_lab.so")       # the same sources with -DLPF_LAB: lpf_set_geometry (tools/, forced-geometry tests)
 SOURCES = ("lpf_api.hip", "lpf_kernels.hip.h", "lpf_reader.hip.h")
 ARCH = "gfx950"
 
@@ -26,23 +27,27 @@ def hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "lpf.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB, os.path.join(CSRC, "lpf_api.hip")]
+def build(force=False, verbose=False, lab=False):
+    """liblpf.so (the product), or with lab=True liblpf_lab.so: the same sources compiled with -DLPF_LAB."""
+    lib = LAB_LIB if lab else LIB
+    if not force and not needs_build(lib):
+        return lib
+    cmd = [hipcc()] + FLAGS + (["-DLPF_LAB"] if lab else []) + ["-o", lib, os.path.join(CSRC, "lpf_api.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, lab="lab" in sys.argv[1:]))

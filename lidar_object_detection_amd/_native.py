@@ -4,6 +4,7 @@ There is no CPU fallback: if the HIP library is missing or no GPU is present the
 calls raise.  NumPy arrays go through the ABI's host-pointer mode; torch CUDA (ROCm)
 tensors are passed by ``data_ptr()`` in device mode.
 """
+import collections
 import ctypes
 import os
 import sys
@@ -46,18 +47,19 @@ class Outputs(ctypes.Structure):
                 ("uv_valid", _P), ("label_valid", _P)]
 
 
-_lib = None
+_libs = {}
 
 
 def library_path():
-    return _build.LIB
+    """liblpf.so of this package; LPF_LIBRARY names another build of the same ABI (lab builds: tools/)."""
+    return os.environ.get("LPF_LIBRARY") or _build.LIB
 
 
-def load():
-    """dlopen liblpf.so; raises if it has not been built (never falls back)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(path=None):
+    """dlopen liblpf.so (or another build of the same ABI at ``path``); raises if it has not been built (never falls back)."""
+    path = os.path.abspath(path or library_path())
+    if path in _libs:
+        return _libs[path]
     # A process that also uses PyTorch must end up with ONE HIP runtime.  The torch wheel bundles its own libamdhip64.so;
     # if liblpf.so pulls in the system copy first, torch's later initialisation fails ("No HIP GPUs are available").
     # Importing torch first makes its copy the one both use (same SONAME).  LPF_NO_TORCH_PRELOAD=1 skips this.
@@ -66,7 +68,6 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-    path = library_path()
     if not os.path.exists(path):
         raise LpfError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU path" % path)
@@ -82,8 +83,8 @@ def load():
     lib.lpf_release_to_stream.argtypes = [_P, _P]
     lib.lpf_sync.argtypes = [_P]
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
-    lib.lpf_set_cu_partition.argtypes = [_P, ctypes.c_int, ctypes.c_int]
-    lib.lpf_set_geometry.argtypes = [_P, ctypes.c_int]
+    if hasattr(lib, "lpf_set_geometry"):                     # lab builds only (-DLPF_LAB)
+        lib.lpf_set_geometry.argtypes = [_P, ctypes.c_int]
     lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -103,6 +104,7 @@ def load():
     lib.lpf_graph_launch.argtypes = [_P, _P]
     lib.lpf_graph_destroy.argtypes = [_P]
     lib.lpf_graph_destroy.restype = None
+    lib.lpf_get_stats.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int]
     lib.lpf_profile_enable.argtypes = [_P, ctypes.c_int]
     lib.lpf_profile_read.argtypes = [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64), ctypes.c_int]
     lib.lpf_profile_overhead.argtypes = [_P, ctypes.POINTER(ctypes.c_double)]
@@ -112,17 +114,16 @@ def load():
     lib.lpf_reader_wait.argtypes = [_P]
     lib.lpf_reader_destroy.argtypes = [_P]
     lib.lpf_reader_destroy.restype = None
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
             "lpf_release_to_stream", "lpf_sync",
-            "lpf_set_pipelined",
-            "lpf_set_cu_partition", "lpf_set_geometry", "lpf_allreduce_metrics",
+            "lpf_set_pipelined", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
             "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
 
@@ -228,8 +229,8 @@ class ScanReader:
 class LpfContext:
     """One context = one GPU + one stream (not thread-safe): the C ABI, object-shaped."""
 
-    def __init__(self, device=0):
-        self._lib = load()
+    def __init__(self, device=0, library=None):
+        self._lib = load(library)
         h = _P()
         rc = self._lib.lpf_create(ctypes.byref(h), int(device))
         if rc != 0:
@@ -241,6 +242,11 @@ class LpfContext:
         self.M = 0
         self.F_masks = 0
         self.box_off = None
+        self._depth = 1
+        # lent tensors (masks, box corners) of the runs that may still read them: in the pipelined modes a run's inputs are read
+        # up to two launches after it was queued, so the references of the last few runs are kept (torch's caching allocator is
+        # ordered with torch's stream, not with this context's)
+        self._lent = collections.deque(maxlen=4)
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc):
@@ -286,25 +292,30 @@ class LpfContext:
 
     def sync(self):
         self._check(self._lib.lpf_sync(self._h))
+        self._lent.clear()
 
-    def set_pipelined(self, on=True, pack_side=False):
-        """Pipelined device-mode runs (lpf_set_pipelined).  ``on="fused"``: the tail of a run rides in the next run's launch
-        (one launch per run, no second stream).  ``on=True``: tail kernels on a second stream; with pack_side the
-        device-mode mask packing too (third stream; the masks must be complete when set_masks is called).
-        ``on="fused-pack"``: as "fused", and the packing of lent uint8 masks rides too -- the launch of a run carries its mask
-        pack, the streaming work of the run before, the tail of the one before that; a run's points and outputs are in use
-        until the launch after the next.  Results of a run are complete after sync() / release_to_stream()."""
-        mode = 4 if on == "fused-pack" else 2 if on == "fused" else ((3 if pack_side else 1) if on else 0)
-        self._check(self._lib.lpf_set_pipelined(self._h, mode))
+    PIPELINED = {False: 0, 0: 0, None: 0, "off": 0, "fused": 2, 2: 2, "fused-pack": 4, 4: 4}
 
-    def set_cu_partition(self, side_cus=0, exclusive=False):
-        """Confine the side streams of the pipelined mode to ``side_cus`` CUs (multiple of 8); with ``exclusive`` the
-        context's own main stream runs on the others."""
-        self._check(self._lib.lpf_set_cu_partition(self._h, int(side_cus), int(bool(exclusive))))
+    def set_pipelined(self, on="fused-pack"):
+        """Software-pipelined device-mode runs (lpf_set_pipelined).  ``"fused"``: the tail of a run rides in the next run's
+        launch (one launch per run).  ``"fused-pack"``: the packing of lent uint8 masks rides too -- the launch of a run carries
+        its mask pack, the streaming work of the run before, the tail of the one before that; a run's points and outputs are in
+        use until the launch after the next.  ``False`` switches it off.  Results of a run are complete after sync() /
+        release_to_stream().  Masks are set before every run; boxes set for a run travel with it (no drain)."""
+        if on is True:
+            raise ValueError('set_pipelined(True) meant the stream-pipelined modes 1 / 3, removed in ABI 5: use "fused" or "fused-pack"')
+        if on not in self.PIPELINED:
+            raise ValueError('set_pipelined: False, "fused" or "fused-pack"')
+        self._check(self._lib.lpf_set_pipelined(self._h, self.PIPELINED[on]))
+        self._depth = 3 if self.PIPELINED[on] else 1
+        self._lent = collections.deque(self._lent, maxlen=2 * self._depth + 2)
 
     def set_geometry(self, mode="auto"):
-        """Segment / tile sizes of a run: "auto" (by launch size), "small" (1024-point segments, wide tail), "small-narrow",
-        "large" (4096) or "large-scan" (4096, prefixes from the scan kernel); same results."""
+        """LAB BUILDS ONLY (LPF_LIBRARY=liblpf_lab.so).  Segment / tile sizes of a run: "auto" (by launch size, what the product
+        does), "small" (1024-point segments, wide tail), "small-narrow", "large" (4096) or "large-scan" (4096, prefixes from
+        the scan kernel); same results."""
+        if not hasattr(self._lib, "lpf_set_geometry"):
+            raise LpfError(-3, "lpf_set_geometry exists in lab builds only (python -m lidar_object_detection_amd._build lab; LPF_LIBRARY=...)")
         self._check(self._lib.lpf_set_geometry(self._h, {"auto": 0, "small": 1, "large": 2, "large-scan": 3, "small-narrow": 4}[mode]))
 
     def allreduce_metrics(self, vec, rccl_comm, op="sum"):
@@ -330,6 +341,14 @@ class LpfContext:
 
     def graph_destroy(self, g):
         self._lib.lpf_graph_destroy(g)
+
+    STATS = ("host_waits", "drains", "uploads", "step_launches", "box_jobs_alone", "box_jobs_riding", "blocking_uploads")
+
+    def stats(self, reset=False):
+        """dict of lpf_get_stats: what the context has done so far (host waits, drains, uploads, launches)."""
+        a = np.zeros(8, np.int64)
+        self._check(self._lib.lpf_get_stats(self._h, a.ctypes.data, 8, int(bool(reset))))
+        return dict(zip(self.STATS, (int(v) for v in a)))
 
     def profile_enable(self, on=True):
         self._check(self._lib.lpf_profile_enable(self._h, int(bool(on))))
@@ -362,8 +381,9 @@ class LpfContext:
         (mask.astype(uint8) != 0, V3:222-225), "v3" (the V3:82-97 erosion block's casts; same as
         v3_pipeline=True) or "gt0.5" (mask > 0.5, Same_color.py:125 / vis.py:185).
         lend=True (GPU tensors): the tensor stays untouched until the runs that use these masks have completed, so a
-        small launch may read it directly instead of packing it first (on_device = 2 of the C ABI); the context keeps
-        a reference to it until the masks are replaced."""
+        small launch may read it directly instead of packing it first, and in the "fused-pack" mode its pack rides in the
+        run's launch (on_device = 2 of the C ABI).  The context keeps references to the lent tensors of the last few runs
+        (until sync() at the latest); the CALLER must not rewrite a lent tensor before the run's results are complete."""
         if binarize is None:
             binarize = "v3" if v3_pipeline else "astype"
         if binarize not in self.BINARIZE:
@@ -392,7 +412,8 @@ class LpfContext:
             rc = self._lib.lpf_set_masks_f32(self._h, ptr, F, M, self.BINARIZE[binarize], int(erode_iters), where)
         else:
             rc = self._lib.lpf_set_masks_u8(self._h, ptr, F, M, int(erode_iters), where)
-        self._lent_masks = keep if (dev and lend) else None
+        if dev and lend:
+            self._lent.append(keep)
         del keep
         self._check(rc)
         self.F_masks, self.M = F, M
@@ -428,12 +449,31 @@ class LpfContext:
                                             len(arrs), int(bool(oriented))))
         self.box_off = off
 
-    def set_boxes_device(self, corners, box_off, oriented=True):
-        """Boxes from a torch float64 GPU tensor [Btot,8,3] (velodyne frame); box_off: host int32 [F+1].  Enqueues one kernel
-        on the context's stream; with unchanged box counts it neither copies nor synchronises (usable inside graph_begin/end)."""
+    def set_boxes_device(self, corners, box_off, oriented=True, lend=False):
+        """Boxes from a torch float64 GPU tensor [Btot,8,3] (velodyne frame); box_off: host int32 [F+1].  No copy through the
+        host and no wait (usable inside graph_begin/end with unchanged box counts).  lend=True: the tensor is read when the
+        tables are built -- by the next run's launch in the pipelined modes -- and must stay unchanged until then."""
         off = np.ascontiguousarray(box_off, dtype=np.int32)
-        self._check(self._lib.lpf_set_boxes_ex(self._h, _dev_ptr(corners, "float64") if int(off[-1]) else None, 1, off.ctypes.data,
+        self._check(self._lib.lpf_set_boxes_ex(self._h, _dev_ptr(corners, "float64") if int(off[-1]) else None, 2 if lend else 1, off.ctypes.data,
                                                off.shape[0] - 1, int(bool(oriented))))
+        if lend:
+            self._lent.append(corners)
+        self.box_off = off
+
+    def set_boxes_cam0_device(self, corners_cam0, box_off, T_cam_to_velo, filter_visible=True, oriented=True, lend=False,
+                              visible=None, corners_velo=None, bbox2d=None, front=None):
+        """set_boxes_cam0 with the cam-0 corners in a torch float64 GPU tensor [Btot,8,3] (and optional GPU output tensors:
+        visible uint8 [Btot], corners_velo float64 [Btot,8,3], bbox2d float64 [Btot,4], front int32 [Btot]).  The reference's
+        per-frame box preparation (V3:556-562) entirely on the device, without a wait; in the pipelined modes it rides in the
+        next run's launch.  lend as in set_boxes_device."""
+        off = np.ascontiguousarray(box_off, dtype=np.int32)
+        T = np.ascontiguousarray(T_cam_to_velo, dtype=np.float64).reshape(16)
+        self._check(self._lib.lpf_set_boxes_cam0(self._h, _dev_ptr(corners_cam0, "float64") if int(off[-1]) else None, 2 if lend else 1,
+                                                 off.ctypes.data, off.shape[0] - 1, T.ctypes.data, int(bool(filter_visible)), int(bool(oriented)),
+                                                 _dev_ptr(visible, "uint8"), _dev_ptr(corners_velo, "float64"), _dev_ptr(bbox2d, "float64"),
+                                                 _dev_ptr(front, "int32")))
+        if lend:
+            self._lent.append(corners_cam0)
         self.box_off = off
 
     def set_boxes_cam0(self, corners_cam0_per_frame, T_cam_to_velo, filter_visible=True, oriented=True, want_outputs=True):
@@ -603,9 +643,16 @@ class LpfContext:
         self._check(self._lib.lpf_run_batch(self._h, _dev_ptr(pts, "float32"), off.ctypes.data, F, 1,
                                             ctypes.byref(o)))
 
-    def make_device_step(self, pts, frame_off, masks_u8=None, erode_iters=0, **outs):
-        """Pre-marshal one device-mode step (optional u8 mask pack + run_batch) and return a
-        zero-argument callable that only performs the C calls -- for launch-bound loops."""
+    def make_device_step(self, pts, frame_off, masks_u8=None, erode_iters=0, lend=False, boxes_cam0=None, box_off=None,
+                         T_cam_to_velo=None, filter_visible=True, oriented=True, **outs):
+        """Pre-marshal one device-mode step -- optional u8 masks, optional per-step boxes (the reference's per-frame box
+        preparation from cam-0 corners, V3:556-562), run_batch -- and return a zero-argument callable that only performs the C
+        calls: for launch-bound loops.
+        lend=False: the mask tensor may be rewritten, in stream order, right after the step call returns (it is packed by a
+        launch of its own at the call).  lend=True passes masks (and box corners) as LENT (on_device = 2): nothing is copied or
+        packed at the call -- in the "fused-pack" mode the pack and the box set-up ride in the step's launch, small sparse launches
+        read the masks directly -- but the tensors must then stay UNCHANGED until the step's results are complete (in the
+        pipelined modes a step's inputs are read up to two launches later)."""
         off = np.ascontiguousarray(frame_off, dtype=np.int64)
         F = off.shape[0] - 1
         o = Outputs()
@@ -622,7 +669,10 @@ class LpfContext:
         o.uv_valid, o.label_valid = _dev_ptr(outs.get("uv_valid"), "int32"), _dev_ptr(outs.get("label_valid"))
         lib, h, check = self._lib, self._h, self._check
         p_pts, p_off, p_out = _P(_dev_ptr(pts, "float32")), _P(off.ctypes.data), ctypes.byref(o)
-        run, setm = lib.lpf_run_batch, lib.lpf_set_masks_u8
+        run, setm, setb = lib.lpf_run_batch, lib.lpf_set_masks_u8, lib.lpf_set_boxes_cam0
+        where = 2 if lend else 1
+        calls = []
+        keep = [off, o, pts, outs]
         if masks_u8 is not None:
             shape = tuple(masks_u8.shape)
             if len(shape) == 3:
@@ -631,16 +681,24 @@ class LpfContext:
                 raise ValueError("masks_u8 must be a torch.uint8 GPU tensor [F,M,H,W]")
             p_m, M, it = _P(_dev_ptr(masks_u8)), shape[1], int(erode_iters)
             self.F_masks, self.M = F, M
+            keep.append(masks_u8)
+            calls.append(lambda: setm(h, p_m, F, M, it, where))
+        if boxes_cam0 is not None:
+            boff = np.ascontiguousarray(box_off, dtype=np.int32)
+            if boff.shape[0] != F + 1:
+                raise ValueError("box_off must have F + 1 entries")
+            Tcv = np.ascontiguousarray(T_cam_to_velo, dtype=np.float64).reshape(16)
+            p_b = _P(_dev_ptr(boxes_cam0, "float64")) if int(boff[-1]) else None
+            p_bo, p_T, fv, ori = _P(boff.ctypes.data), _P(Tcv.ctypes.data), int(bool(filter_visible)), int(bool(oriented))
+            self.box_off = boff
+            keep += [boxes_cam0, boff, Tcv]
+            calls.append(lambda: setb(h, p_b, where, p_bo, F, p_T, fv, ori, None, None, None, None))
+        calls.append(lambda: run(h, p_pts, p_off, F, 1, p_out))
+        calls = tuple(calls)
 
-            def fn(_keep=(off, o, pts, masks_u8, outs)):
-                rc = setm(h, p_m, F, M, it, 2)               # lent: the closure holds the tensor, and the run follows at once
-                if rc == 0:
-                    rc = run(h, p_pts, p_off, F, 1, p_out)
-                if rc:
-                    check(rc)
-        else:
-            def fn(_keep=(off, o, pts, outs)):
-                rc = run(h, p_pts, p_off, F, 1, p_out)
+        def fn(_keep=tuple(keep)):
+            for call in calls:
+                rc = call()
                 if rc:
                     check(rc)
         return fn

@@ -47,10 +47,12 @@ struct lpf_graph {
     unsigned long long generation = 0;    // lpf_ctx::generation at capture time
 };
 
+#define LPF_NSETS 4                   // scratch sets / box sets in rotation (mode 4 keeps four runs in flight)
+
 struct lpf_ctx {
     bool capturing = false;
-    // Bumped by everything a captured graph bakes in and a later call may invalidate: buffer regrowth, frame-table
-    // upload, box / camera / stream / pipelining changes.  lpf_graph_launch refuses a graph of another generation.
+    // Bumped by everything a captured graph bakes in and a later call may invalidate: buffer regrowth, table
+    // uploads, box / camera / stream / pipelining changes.  lpf_graph_launch refuses a graph of another generation.
     unsigned long long generation = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -69,35 +71,47 @@ struct lpf_ctx {
     // a small launch reads them directly in K1 (LpfDirect), anything else packs them first (ensure_packed).
     struct Lazy { bool valid = false; const void *p = nullptr; bool f32 = false; int mode = 0; } lazy;
 
-    // boxes
-    int box_F = 0, oriented = 1;
-    std::vector<int32_t> box_off;     // F+1
-    DevBuf boxp;                      // [Btot][16] double
-    DevBuf boxq;                      // [Btot][8] float conservative AABB
-    DevBuf cand;                      // candidate-box grid (lpf_box_setup_kernel)
-    DevBuf box_corners;               // [Btot][8][3] velodyne-frame corners the tables were built from (kept: a camera change rebuilds them)
-    DevBuf box_enabled;               // [Btot] bytes: 0 = dropped by filter_visible_bboxes (lpf_set_boxes_cam0), else null
-    DevBuf box_frames;                // [F] LpfBoxFrame
-    DevBuf box_aux;                   // lpf_set_boxes_cam0: projected 2D boxes + front counts
-    bool have_enabled = false;
-    std::vector<LpfBoxFrame> h_bframes, h_bframes_dev;
-    std::vector<long long> cand_off;  // [F] first word of frame f's grid
-    size_t cand_words = 0;            // words of the whole grid
-    bool cand_dirty = true;           // the tables must be (re)built from box_corners before the next run
+    // Boxes.  A ring of box sets: in the software-pipelined modes the tail that counts into the boxes of run i executes one
+    // or two launches after run i was queued, so a lpf_set_boxes* for the NEXT run must not touch the tables run i's tail is
+    // going to read -- it takes the next set of the ring instead (no drain, no synchronisation), and the preparation of its
+    // tables (LpfBoxJob) rides in that run's launch.  Serial mode stays on one set: the stream orders everything.
+    struct BoxSet {
+        int F = 0, oriented = 1;
+        std::vector<int32_t> box_off;             // F+1
+        std::vector<LpfBoxFrame> h_bframes, h_bframes_dev;   // per-frame records: being built / in HBM (F > 1 only)
+        std::vector<long long> cand_off;          // [F] first word of frame f's grid
+        size_t cand_words = 0;                    // words of the whole grid
+        DevBuf boxp;                              // [Btot][16] double
+        DevBuf boxq;                              // [Btot][8] float conservative AABB
+        DevBuf cand;                              // candidate-box grid
+        DevBuf corners;                           // [Btot][8][3] velodyne-frame corners the tables were built from (kept: a camera change rebuilds them)
+        DevBuf enabled;                           // [Btot] bytes: 0 = dropped by filter_visible_bboxes (lpf_set_boxes_cam0)
+        DevBuf aux;                               // lpf_set_boxes_cam0 for host callers: projected 2D boxes + front counts
+        DevBuf bframes;                           // [F] LpfBoxFrame
+        DevBuf stage;                             // corners copied from the caller (host memory, or device memory that is not lent)
+        bool have_enabled = false;
+        bool used = false;                        // a run has been queued with these tables since they were set
+        long long last_ref = -1;                  // ... the last such run (lpf_ctx::run_seq)
+        bool job_valid = false;                   // tables not built yet: the job rides in the next run's launch (or is launched by it)
+        LpfBoxJob job;
+    } bx[LPF_NSETS];
+    int box_cur = 0;
+    bool cand_dirty = false;          // the camera changed since the current set's tables were built: rebuild from its corners
 
-    // per-run scratch
-    DevBuf frames, segs, blks;
-    // Scratch of one in-flight run.  Two sets: with pipelining on, the tail kernels of run i (second
-    // stream) overlap the streaming kernel of run i+1 (caller's stream), which uses the other set.
+    // Scratch of one in-flight run, including its geometry tables (frame records, per-segment frame records, tail block table):
+    // a run whose batch shape differs from the previous one's uploads its own tables -- through the pinned ring below, in stream
+    // order, without waiting -- instead of draining the pipeline to rewrite shared ones.  A launch of ONE frame needs no table.
     struct Scratch {
         DevBuf vbal, mbal, seg_tab, grp_tab, frm_tab, seg_pre, cnt, mlist;
         DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
         void *label_cur = nullptr;
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
-        hipEvent_t k1_done = nullptr, tail_done = nullptr, mask_done = nullptr;
-        bool tail_pending = false, k1_recorded = false, mask_pending = false;
-    } sc[4];
+        DevBuf tab;                   // [frames | segs | blks]
+        std::vector<LpfFrame> tab_frames;         // the frame table `tab` holds (empty: none)
+        size_t o_segs = 0, o_blks = 0;
+    } sc[LPF_NSETS];
     int parity = 0;
+    long long run_seq = 0;            // runs queued so far
     // Software-pipelined modes (lpf_set_pipelined 2 / 4): what earlier runs still owe.  The tail of the last run and the
     // summaries of the one before ride in the next run's launch (lpf_step_t) -- in mode 4 the last run's streaming kernel
     // too (pend_k1) -- or are launched by flush_pending().
@@ -111,27 +125,29 @@ struct lpf_ctx {
         bool direct = false;              // its tiles read the lent masks themselves (LpfDirect; small launches)
         int dsel = 0;                     // ... under membership rule 0 (uint8) or 1..3 (float)
     } pend_k1, pend_tail, pend_fin;
-    bool fused = false;
+    bool fused = false;               // pipelined: one launch per run (modes 2 / 4)
     // Mode 4: the mask pack rides as well -- the launch of run i carries the pack of run i's masks, the K1 tiles of run i-1
     // (pend_k1), the tail of run i-2 and the summaries of run i-3; four scratch sets.
     bool defer = false;
     // Lent masks of a software-pipelined context that have not been packed: the next run decides -- a small launch reads them
     // directly, a large one in mode 4 lets their pack ride in its launch (uint8, 16-byte aligned planes), anything else packs now.
     struct Ride { bool valid = false; const void *masks = nullptr; bool f32 = false, can_ride = false; int mode = 0, F = 0, M = 0; void *label = nullptr; } ride;
-    int geometry = 0;                 // lpf_set_geometry: 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes
-    bool pipelined = false;
-    bool pack_side = false;           // pipelined mode: mask packing on stream_c (overlaps the previous run's streaming kernel)
-    int tail_cus = 0;                 // > 0: stream_b / stream_c are confined to this many CUs (lpf_set_cu_partition)
-    bool cu_exclusive = false;        // ... and the context's own main stream to the others
-    hipStream_t stream_b = nullptr;   // tail kernels (pipelined mode)
-    hipStream_t stream_c = nullptr;   // mask packing (pipelined mode)
+    // lpf_get_stats: [0] host waits, [1] drains (owed work launched outside a run), [2] uploads through the pinned ring, [3] step
+    // launches, [4] box jobs launched as a kernel of their own, [5] box jobs that rode in a step launch, [6] blocking uploads
+    long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int geometry = 0;                 // LPF_LAB builds (lpf_set_geometry): 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes, 4 small + narrow tail
+
+    // Pinned host ring for small uploads (tables, host corners) that must not block: the source of an asynchronous copy has to
+    // stay put until the copy has executed, so each upload takes the next piece of the ring; a quarter of the ring is reused only
+    // after an event recorded when it was left has completed (one event per 2 MB of uploads, not per upload).
+    struct PinRing { char *base = nullptr; size_t cap = 0, head = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool rec[4] = {false, false, false, false}; } ring;
+
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out, boxprep, dimg, coll;
     DevBuf st_uvv, st_labv;
     DevBuf st_pts, st_uv, st_label, st_depth, st_uf, st_vf, st_valid, st_inst, st_count, st_summary;
-    std::vector<LpfFrame> h_frames, h_frames_dev;   // table being built / table currently in HBM
-    std::vector<LpfFrame> h_segs;
-    std::vector<int2> h_blks;         // tail block table (see lpf_tail_t)
+    std::vector<LpfFrame> h_frames;   // table being built
+    std::vector<char> h_tab;          // [frames | segs | blks] being built
 
     // optional event bracketing of K1 (lpf_profile_*)
     bool profiling = false;
@@ -168,20 +184,53 @@ int fail(lpf_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                     \
     } while (0)
 
-// the narrow tail kernel (serial and stream-pipelined modes)
+hipError_t host_wait(lpf_ctx *c)        // the host blocks until the context's stream is idle (counted: lpf_get_stats)
+{
+    ++c->stats[0];
+    return hipStreamSynchronize(c->stream);
+}
+
+// the narrow tail kernel (serial mode)
 void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
 {
     if (pre) hipLaunchKernelGGL((lpf_tail_t<true>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
     else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
 }
 
+#define LPF_CELL_SHIFT 5
+
+// camera-dependent fields of a box job: filled when the job is launched, so a job that waits for its run always sees the
+// camera of that run
+void box_job_camera(const lpf_ctx *c, LpfBoxJob &J)
+{
+    memcpy(J.T, c->T, sizeof J.T);
+    memcpy(J.K, c->K, sizeof J.K);
+    J.W = c->W; J.H = c->H; J.cell_shift = LPF_CELL_SHIFT;
+    J.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT; J.cell_h = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
+}
+
+// the box job of a set as a kernel of its own, on the context's stream (serial mode, graph capture, drains)
+int launch_box_job(lpf_ctx *c, lpf_ctx::BoxSet &B)
+{
+    if (!B.job_valid) return LPF_OK;
+    B.job_valid = false;
+    if (B.F == 0 || B.box_off[B.F] == 0) return LPF_OK;
+    box_job_camera(c, B.job);
+    ++c->stats[4];
+    hipLaunchKernelGGL(lpf_box_job_kernel, dim3((unsigned)B.F), dim3(LPF_BLOCK), 0, c->stream, B.job);
+    LPF_HIP(c, hipGetLastError());
+    return LPF_OK;
+}
+
 // One launch of lpf_step_t: the streaming tiles of run K, the tail blocks of run Q dealt out among them, the summaries of
-// run R and -- mode 4 -- the pack of the masks waiting in c->ride behind the tiles (label elements of pack_lb bytes; K's when
-// K is there: the host keeps the two equal).  Any of the roles may be absent.  `after` is recorded behind the launch.
+// run R, the box job X of the run being queued (a block per frame, in front) and -- mode 4 -- the pack of the masks waiting
+// in c->ride behind the tiles (label elements of pack_lb bytes; K's when K is there: the host keeps the two equal).  Any of
+// the roles may be absent.  `after` is recorded behind the launch.
 int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &Q, const lpf_ctx::Pending &R, bool ride, int pack_lb,
-                hipEvent_t after)
+                lpf_ctx::BoxSet *XB, hipEvent_t after)
 {
     static const LpfParams none = {};                      // unused roles get a well-formed struct
+    static const LpfBoxJob nojob = {};
     const LpfParams &KP = KK.valid ? KK.P : none, &QP = Q.valid ? Q.P : none, &RP = R.valid ? R.P : none;
     const int k_lb = KK.valid ? KK.lb : pack_lb;
     LpfStepLayout Y;
@@ -189,6 +238,12 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     memset(&J, 0, sizeof J);
     Y.nfin = R.valid ? R.P.F : 0;
     Y.nfin8 = (Y.nfin + 7) & ~7;
+    const bool boxes = XB && XB->job_valid && XB->F > 0 && XB->box_off[XB->F] > 0;
+    if (XB) XB->job_valid = false;
+    if (boxes) box_job_camera(c, XB->job);
+    const LpfBoxJob &XJ = boxes ? XB->job : nojob;
+    Y.nbox = boxes ? XB->F : 0;
+    Y.nbox8 = (Y.nbox + 7) & ~7;
     Y.ntail = Q.valid ? Q.ntail : 0;
     Y.nk1 = KK.valid ? KK.nk1 : 0;
     Y.npack = 0;
@@ -209,10 +264,13 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     }
     const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
     Y.rest = (int)(rest > 0 ? rest : 0);
-    const long long grid = (long long)Y.nfin8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
+    const long long grid = (long long)Y.nfin8 + Y.nbox8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
     if (grid > 0) {
         const dim3 gs((unsigned)grid);
-#define LPF_STEP_LAUNCH(RW, LT, PR) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J)
+        ++c->stats[3];
+        if (boxes) ++c->stats[5];
+#define LPF_STEP_LAUNCH(RW, LT, PR) do { if (boxes) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, true>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ); \
+                                         else hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, false>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ); } while (0)
 #define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
         const bool qpre = Q.valid && Q.pre;
         const int rows = KP.tile_pts >> 8;
@@ -237,30 +295,33 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     return LPF_OK;
 }
 
-// software-pipelined modes: launch what earlier runs still owe -- the same step launches, with fewer roles each time
+bool anything_owed(const lpf_ctx *c) { return c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid; }
+
+// software-pipelined modes: launch what earlier runs still owe -- the same step launches, with fewer roles each time; a box job
+// that was waiting for its run goes with the first of them (or alone)
 int flush_pending(lpf_ctx *c)
 {
-    while (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid) {
+    lpf_ctx::BoxSet *XB = &c->bx[c->box_cur];
+    if (anything_owed(c)) ++c->stats[1];
+    while (anything_owed(c)) {
         const lpf_ctx::Pending K = c->pend_k1, Q = c->pend_tail, R = c->pend_fin;
-        int rc_ = launch_step(c, K, Q, R, false, 4, nullptr);
+        int rc_ = launch_step(c, K, Q, R, false, 4, XB, nullptr);
         if (rc_) return rc_;
         c->pend_fin = Q;                   // its tail has just been launched: summaries next
         c->pend_tail = K;
         c->pend_k1.valid = false;
     }
-    return LPF_OK;
+    return launch_box_job(c, *XB);
 }
 
-int sync_all(lpf_ctx *c)                // every stream idle, nothing owed: shared tables / buffers may be rewritten
+int sync_all(lpf_ctx *c)                // the stream idle, nothing owed: any table / buffer may be rewritten or freed
 {
-    if (!c->capturing && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid)) { int rc_ = flush_pending(c); if (rc_) return rc_; }
     if (c->capturing)
         return fail(c, LPF_ERR_STATE, "this call needs a synchronisation or (re)allocation, which cannot be captured into a graph: "
                                       "run the same shapes once before lpf_graph_begin");
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->stream_b) LPF_HIP(c, hipStreamSynchronize(c->stream_b));
-    if (c->stream_c) LPF_HIP(c, hipStreamSynchronize(c->stream_c));
-    for (auto &S : c->sc) { S.tail_pending = false; S.k1_recorded = false; S.mask_pending = false; }
+    { int rc_ = flush_pending(c); if (rc_) return rc_; }
+    LPF_HIP(c, host_wait(c));
+    for (bool &r : c->ring.rec) r = false;                  // every upload has executed
     return LPF_OK;
 }
 
@@ -299,52 +360,64 @@ int use_device(lpf_ctx *c)
     return LPF_OK;
 }
 
-// box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) plus a
-// conservative float AABB of the accepted region, used only to skip hopeless (point, box) pairs.
-void box_params(const double *c, int oriented, double *o, float *q, double *verts = nullptr, char *bounded_out = nullptr)
+// `bytes` of host memory -> device memory `dst`, in stream order, WITHOUT waiting: the data is copied into the pinned ring
+// (which an asynchronous copy may read from whenever it executes) and the copy is queued from there.  Only an upload larger
+// than a quarter of the ring takes the blocking route: everything owed is launched, the stream drained, the copy made.
+#define LPF_RING_BYTES (8u << 20)
+int upload(lpf_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return LPF_OK;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "a table upload cannot be captured into a graph: run the same shapes once before lpf_graph_begin");
+    lpf_ctx::PinRing &R = c->ring;
+    if (!R.base) {
+        LPF_HIP(c, hipHostMalloc((void **)&R.base, LPF_RING_BYTES, hipHostMallocDefault));
+        R.cap = LPF_RING_BYTES; R.head = 0;
+        for (hipEvent_t &e : R.ev) LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t q = R.cap / 4, need = (bytes + 255) & ~(size_t)255;
+    if (need > q) {
+        int rc_ = sync_all(c);
+        if (rc_) return rc_;
+        LPF_HIP(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        ++c->stats[6];
+        return LPF_OK;
+    }
+    size_t cur = R.head / q;
+    if (R.head - cur * q + need > q) {                      // leave this quarter: it is reusable once what was queued from it has run
+        LPF_HIP(c, hipEventRecord(R.ev[cur], c->stream));
+        R.rec[cur] = true;
+        cur = (cur + 1) & 3;
+        R.head = cur * q;
+        if (R.rec[cur]) {
+            if (hipEventQuery(R.ev[cur]) != hipSuccess) { ++c->stats[0]; LPF_HIP(c, hipEventSynchronize(R.ev[cur])); }
+            R.rec[cur] = false;
+        }   // a full lap of uploads ago: long done
+    }
+    char *h = R.base + R.head;
+    R.head += need;
+    memcpy(h, src, bytes);
+    ++c->stats[2];
+    LPF_HIP(c, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return LPF_OK;
+}
+
+// box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) for lpf_points_in_boxes
+void box_params(const double *c, int oriented, double *o)
 {
     for (int i = 0; i < 16; ++i) o[i] = 0.0;
-    double lo[3], hi[3];
-    bool bounded = true;
     if (oriented) {
         static const int other[3] = {1, 3, 4};
         o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
-        double V[3][3], vv[3];
         bool ok = true;
         for (int a = 0; a < 3; ++a) {
             const double *p = c + 3 * other[a];
             const double v0 = p[0] - c[0], v1 = p[1] - c[1], v2 = p[2] - c[2];
             double w = v0 * v0; w = std::fma(v1, v1, w); w = std::fma(v2, v2, w);
             o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = w;
-            V[a][0] = v0; V[a][1] = v1; V[a][2] = v2; vv[a] = w;
             if (!(w >= 1e-100 && w <= 1e100)) ok = false;      // also false for NaN; the range in which the kernel's
                                                                // division-free slab test is provably the quotient test (see lpf_oriented_inside)
         }
         o[15] = ok ? 1.0 : 0.0;            // 1: "0 <= d <= vv" decides the slab exactly (see kernel comment)
-        // region = { p : 0 <= (p-c0).v_a <= vv_a }: vertices solve V x = sigma*vv, sigma in {0,1}^3
-        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
-                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
-        const double scale = std::sqrt(vv[0]) * std::sqrt(vv[1]) * std::sqrt(vv[2]);
-        if (!ok || !(std::fabs(det) > 1e-6 * scale)) {
-            bounded = false;
-        } else {
-            double inv[3][3];
-            inv[0][0] = (V[1][1] * V[2][2] - V[1][2] * V[2][1]) / det; inv[0][1] = (V[0][2] * V[2][1] - V[0][1] * V[2][2]) / det;
-            inv[0][2] = (V[0][1] * V[1][2] - V[0][2] * V[1][1]) / det; inv[1][0] = (V[1][2] * V[2][0] - V[1][0] * V[2][2]) / det;
-            inv[1][1] = (V[0][0] * V[2][2] - V[0][2] * V[2][0]) / det; inv[1][2] = (V[0][2] * V[1][0] - V[0][0] * V[1][2]) / det;
-            inv[2][0] = (V[1][0] * V[2][1] - V[1][1] * V[2][0]) / det; inv[2][1] = (V[0][1] * V[2][0] - V[0][0] * V[2][1]) / det;
-            inv[2][2] = (V[0][0] * V[1][1] - V[0][1] * V[1][0]) / det;
-            for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
-            for (int sg = 0; sg < 8; ++sg) {
-                const double r[3] = {(sg & 1) ? vv[0] : 0.0, (sg & 2) ? vv[1] : 0.0, (sg & 4) ? vv[2] : 0.0};
-                for (int k = 0; k < 3; ++k) {
-                    const double x = c[k] + inv[k][0] * r[0] + inv[k][1] * r[1] + inv[k][2] * r[2];
-                    if (verts) verts[3 * sg + k] = x;
-                    if (x < lo[k]) lo[k] = x;
-                    if (x > hi[k]) hi[k] = x;
-                }
-            }
-        }
     } else {
         for (int k = 0; k < 3; ++k) {
             double a = c[k], b = c[k];
@@ -353,52 +426,15 @@ void box_params(const double *c, int oriented, double *o, float *q, double *vert
                 if (w < a) a = w;
                 if (w > b) b = w;
             }
-            o[k] = a; o[3 + k] = b; lo[k] = a; hi[k] = b;
-            if (!(a == a) || !(b == b)) bounded = false;
-        }
-        if (verts)
-            for (int sg = 0; sg < 8; ++sg)
-                for (int k = 0; k < 3; ++k) verts[3 * sg + k] = ((sg >> k) & 1) ? hi[k] : lo[k];
-    }
-    for (int k = 0; k < 3; ++k) if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) bounded = false;
-    if (bounded_out) *bounded_out = bounded ? 1 : 0;
-    for (int k = 0; k < 3; ++k) {
-        if (!bounded || !std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
-            q[k] = -INFINITY; q[4 + k] = INFINITY;
-        } else {
-            const double m = 1e-5 * (std::fabs(lo[k]) + std::fabs(hi[k]) + (hi[k] - lo[k])) + 1e-6;
-            q[k] = std::nextafterf((float)(lo[k] - m), -INFINITY);
-            q[4 + k] = std::nextafterf((float)(hi[k] + m), INFINITY);
+            o[k] = a; o[3 + k] = b;
         }
     }
-    q[3] = 0.f; q[7] = 0.f;
 }
 
-#define LPF_CELL_SHIFT 5
-// Box tables from the corners kept in box_corners: parameters, float bounds and the candidate grid, all on the device
-// (lpf_box_setup_kernel), on the context's stream, with no host work and no synchronisation -- capturable.
-int launch_box_setup(lpf_ctx *c)
-{
-    const int F = c->box_F, Btot = F ? c->box_off[F] : 0;
-    c->cand_dirty = false;
-    if (Btot == 0) return LPF_OK;
-    LpfBoxSetup A;
-    memcpy(A.T, c->T, sizeof A.T);
-    memcpy(A.K, c->K, sizeof A.K);
-    A.W = c->W; A.H = c->H; A.cell_shift = LPF_CELL_SHIFT;
-    A.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT; A.cell_h = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
-    A.oriented = c->oriented; A.F = F; A.Btot = Btot;
-    LPF_HIP(c, hipMemsetAsync(c->cand.p, 0, c->cand_words * 8, c->stream));
-    hipLaunchKernelGGL(lpf_box_setup_kernel, dim3((unsigned)((Btot + 3) / 4)), dim3(LPF_BLOCK), 0, c->stream, A,
-                       (const double *)c->box_corners.p, c->have_enabled ? (const uint8_t *)c->box_enabled.p : nullptr,
-                       (const LpfBoxFrame *)c->box_frames.p, (double *)c->boxp.p, (float *)c->boxq.p, (unsigned long long *)c->cand.p);
-    LPF_HIP(c, hipGetLastError());
-    return LPF_OK;
-}
-
-// Shapes of a box set: per-frame records, grid offsets, buffers.  The per-frame table only goes to the device when it
-// changed (then with a synchronisation, like the frame table of lpf_run_batch); otherwise nothing here blocks.
-int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const char *who)
+// The box set a lpf_set_boxes* call writes: in the software-pipelined modes the next one of the ring once the current one has
+// been used by a run (its tables are still to be read by that run's tail), else the current one.  Then its shapes: per-frame
+// records, grid offsets, buffers.  Nothing here waits for the GPU unless a buffer has to grow.
+int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const char *who, lpf_ctx::BoxSet **out)
 {
     if (F < 0 || (F > 0 && !box_off)) return fail(c, LPF_ERR_ARG, "%s: F=%d box_off=%p", who, F, (const void *)box_off);
     if (F > 0 && box_off[0] != 0) return fail(c, LPF_ERR_ARG, "%s: box_off[0] must be 0", who);
@@ -406,38 +442,119 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
         if (box_off[f + 1] < box_off[f]) return fail(c, LPF_ERR_ARG, "%s: box_off not ascending at %d", who, f);
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "%s: lpf_set_camera must be called first (the candidate grid is per image cell)", who);
     int rc;
-    // pipelined modes: the tail of a run already queued / still owed reads the box tables -> drain first
-    if ((c->pipelined || c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid) && !c->capturing && (rc = sync_all(c))) return rc;
+    lpf_ctx::BoxSet *B = &c->bx[c->box_cur];
+    if (c->fused && !c->capturing) {
+        if (B->used) {
+            B->job_valid = false;                          // (cannot be: a run launches the job of the set it uses)
+            c->box_cur = (c->box_cur + 1) % LPF_NSETS;
+            B = &c->bx[c->box_cur];
+        }
+        // the tail of the last run that used this set's old tables must have been LAUNCHED before they are rewritten (in stream
+        // order); with one set per run and four sets it always has -- else launch what is owed first (still no host wait)
+        const int depth = c->defer ? 2 : 1;
+        if (B->last_ref >= 0 && B->last_ref + depth >= c->run_seq && (rc = flush_pending(c))) return rc;
+    }
+    B->used = false; B->last_ref = -1; B->job_valid = false; B->F = 0;
     const int cw = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT, ch = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     const size_t ncell = (size_t)cw * ch;
-    c->h_bframes.resize((size_t)F);
-    c->cand_off.assign((size_t)F, 0);
+    B->h_bframes.resize((size_t)F);
+    B->cand_off.assign((size_t)F, 0);
     size_t total = 0;
     for (int f = 0; f < F; ++f) {
-        const int B = box_off[f + 1] - box_off[f];
-        c->h_bframes[f].box_off = box_off[f]; c->h_bframes[f].B = B; c->h_bframes[f].cand_off = (long long)total;
-        c->cand_off[f] = (long long)total;
-        total += ncell * (size_t)((B + 63) / 64);
+        const int nb = box_off[f + 1] - box_off[f];
+        B->h_bframes[f].box_off = box_off[f]; B->h_bframes[f].B = nb; B->h_bframes[f].cand_off = (long long)total;
+        B->cand_off[f] = (long long)total;
+        total += ncell * (size_t)((nb + 63) / 64);
     }
     const int Btot = F ? box_off[F] : 0;
-    if ((rc = reserve(c, c->boxp, (size_t)(Btot ? Btot : 1) * 16 * sizeof(double)))) return rc;
-    if ((rc = reserve(c, c->boxq, (size_t)(Btot ? Btot : 1) * 8 * sizeof(float)))) return rc;
-    if ((rc = reserve(c, c->cand, (total ? total : 1) * 8))) return rc;
-    if ((rc = reserve(c, c->box_corners, (size_t)(Btot ? Btot : 1) * 24 * sizeof(double)))) return rc;
-    if ((rc = reserve(c, c->box_frames, (size_t)(F ? F : 1) * sizeof(LpfBoxFrame)))) return rc;
-    if (c->h_bframes_dev.size() != c->h_bframes.size() ||
-        (F && memcmp(c->h_bframes_dev.data(), c->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame)) != 0)) {
-        if ((rc = sync_all(c))) return rc;
-        if (F) {
-            LPF_HIP(c, hipMemcpyAsync(c->box_frames.p, c->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame), hipMemcpyHostToDevice, c->stream));
-            LPF_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t nb = (size_t)(Btot ? Btot : 1);
+    if ((rc = reserve(c, B->boxp, nb * 16 * sizeof(double)))) return rc;
+    if ((rc = reserve(c, B->boxq, nb * 8 * sizeof(float)))) return rc;
+    if ((rc = reserve(c, B->cand, (total ? total : 1) * 8))) return rc;
+    if ((rc = reserve(c, B->corners, nb * 24 * sizeof(double)))) return rc;
+    if ((rc = reserve(c, B->enabled, nb))) return rc;
+    if (F > 1) {
+        if ((rc = reserve(c, B->bframes, (size_t)F * sizeof(LpfBoxFrame)))) return rc;
+        if (B->h_bframes_dev.size() != B->h_bframes.size() ||
+            memcmp(B->h_bframes_dev.data(), B->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame)) != 0) {
+            if ((rc = upload(c, B->bframes.p, B->h_bframes.data(), (size_t)F * sizeof(LpfBoxFrame)))) return rc;
+            B->h_bframes_dev = B->h_bframes;
+            ++c->generation;                                  // graphs captured for other box counts index these tables
         }
-        c->h_bframes_dev = c->h_bframes;
-        ++c->generation;                                  // graphs captured for other box counts index these tables
     }
-    c->cand_words = total;
-    c->box_off.assign(box_off, box_off + F + 1);
-    c->box_F = F; c->oriented = oriented ? 1 : 0;
+    B->cand_words = total;
+    B->box_off.assign(box_off, box_off + F + 1);
+    B->F = F; B->oriented = oriented ? 1 : 0;
+    *out = B;
+    return LPF_OK;
+}
+
+// the job that (re)builds a set's tables from its own copy of the velodyne-frame corners (the camera changed)
+void box_rebuild_job(lpf_ctx::BoxSet &B)
+{
+    LpfBoxJob &J = B.job;
+    memset(&J, 0, sizeof J);
+    J.src = (const double *)B.corners.p;
+    J.enabled_in = B.have_enabled ? (const uint8_t *)B.enabled.p : nullptr;
+    J.oriented = B.oriented; J.F = B.F;
+    J.bframes = (const LpfBoxFrame *)B.bframes.p;
+    if (B.F > 0) J.frame0 = B.h_bframes[0];
+    J.boxp = (double *)B.boxp.p; J.boxq = (float *)B.boxq.p; J.cand = (unsigned long long *)B.cand.p;
+    B.job_valid = true;
+}
+
+// lpf_set_boxes_ex / lpf_set_boxes_cam0: corners (velodyne or cam-0 frame) -> the job that builds the set's tables.  The job is
+// launched here when the caller wants results in host memory (then the call waits for them), in serial mode and inside a graph
+// capture; a software-pipelined context leaves it to the next lpf_run*, in whose launch it rides.
+int set_boxes_impl(lpf_ctx *c, const double *corners, int on_device, const int32_t *box_off, int F, int oriented, bool cam0, const double *Tcv,
+                   int filter_visible, uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front, const char *who)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (on_device < 0 || on_device > 2) return fail(c, LPF_ERR_ARG, "%s: on_device=%d (0 host, 1 device, 2 device and lent)", who, on_device);
+    if (F == 0) { lpf_ctx::BoxSet &B0 = c->bx[c->box_cur]; B0.F = 0; B0.box_off.clear(); B0.job_valid = false; return LPF_OK; }
+    if (cam0 && !Tcv) return fail(c, LPF_ERR_ARG, "%s: T_cam_to_velo is NULL", who);
+    if (box_off && F > 0 && box_off[F] > 0 && !corners) return fail(c, LPF_ERR_ARG, "%s: corners is NULL", who);
+    int rc;
+    lpf_ctx::BoxSet *B = nullptr;
+    if ((rc = box_layout(c, box_off, F, oriented, who, &B))) return rc;
+    const int Btot = box_off[F];
+    B->have_enabled = cam0 && filter_visible != 0;
+    c->cand_dirty = false;                                 // the job reads the camera when it is launched
+    if (Btot == 0) return LPF_OK;
+    const size_t nb = (size_t)Btot;
+    const double *src = corners;
+    if (on_device != 2) {                                  // not lent: the context's own copy, made in stream order
+        if ((rc = reserve(c, B->stage, nb * 192))) { B->F = 0; return rc; }
+        if (on_device) LPF_HIP(c, hipMemcpyAsync(B->stage.p, corners, nb * 192, hipMemcpyDeviceToDevice, c->stream));
+        else if ((rc = upload(c, B->stage.p, corners, nb * 192))) { B->F = 0; return rc; }
+        src = (const double *)B->stage.p;
+    }
+    const bool host_out = !on_device && (visible || corners_velo || bbox2d || front);
+    if (host_out && (rc = reserve(c, B->aux, nb * 36))) { B->F = 0; return rc; }
+    LpfBoxJob &J = B->job;
+    memset(&J, 0, sizeof J);
+    J.src = src; J.cam0 = cam0 ? 1 : 0; J.filter_visible = filter_visible ? 1 : 0; J.oriented = B->oriented; J.F = F;
+    if (cam0) memcpy(J.Tcv, Tcv, sizeof J.Tcv);
+    J.bframes = (const LpfBoxFrame *)B->bframes.p; J.frame0 = B->h_bframes[0];
+    J.boxp = (double *)B->boxp.p; J.boxq = (float *)B->boxq.p; J.cand = (unsigned long long *)B->cand.p;
+    J.corners_keep = (double *)B->corners.p;
+    if (cam0) {
+        J.enabled_out = (uint8_t *)B->enabled.p;
+        if (on_device) { J.visible = visible; J.corners_out = corners_velo; J.bbox2d = bbox2d; J.front = front; }
+        else if (host_out) { J.bbox2d = (double *)B->aux.p; J.front = (int32_t *)((char *)B->aux.p + nb * 32); }
+    }
+    B->job_valid = true;
+    if (host_out || !c->fused || c->capturing) {
+        if ((rc = launch_box_job(c, *B))) return rc;
+    }
+    if (host_out) {
+        if (visible) LPF_HIP(c, hipMemcpyAsync(visible, B->enabled.p, nb, hipMemcpyDeviceToHost, c->stream));
+        if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, B->corners.p, nb * 192, hipMemcpyDeviceToHost, c->stream));
+        if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, B->aux.p, nb * 32, hipMemcpyDeviceToHost, c->stream));
+        if (front) LPF_HIP(c, hipMemcpyAsync(front, (char *)B->aux.p + nb * 32, nb * 4, hipMemcpyDeviceToHost, c->stream));
+        LPF_HIP(c, host_wait(c));       // the caller's host buffers are filled on return
+    }
     return LPF_OK;
 }
 
@@ -500,27 +617,18 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called before masks (W, H)");
     if (F < 0 || M < 0 || M > LPF_MAX_MASKS || erode_iters < 0 || (F > 0 && M > 0 && !masks))
         return fail(c, LPF_ERR_ARG, "set_masks: F=%d M=%d erode_iters=%d masks=%p", F, M, erode_iters, (const void *)masks);
-    // Pipelined + device masks: pack on the third stream into the label buffers of the scratch set
-    // the next run will use, so it overlaps the current run's streaming kernel.
-    // (Measured: packing on a side stream competes with the streaming kernel for HBM and lowers
-    //  both the step rate and that kernel's bandwidth -- 136 vs 142 Gpoints/s -- so the pack stays on
-    //  the caller's stream; the per-set label buffers keep the option open.)
-    const bool side = c->pack_side;
-    const bool pipe = side && c->pipelined && on_device && !c->capturing;
-    const bool per_set = c->pipelined && on_device && !c->capturing;
+    // software-pipelined modes + device masks: the label images rotate with the scratch sets (the tiles of the previous run may
+    // still have to read theirs); anything else uses set 0, with nothing owed
+    const bool per_set = c->fused && on_device && !c->capturing;
     int rc;
-    if (!per_set && (c->stream_b || c->stream_c) && (c->sc[0].tail_pending || c->sc[1].tail_pending || c->sc[0].mask_pending ||
-                                                      c->sc[1].mask_pending) && (rc = sync_all(c))) return rc;
+    if (!per_set && anything_owed(c) && (rc = sync_all(c))) return rc;    // owed tiles read set 0's label image / the staging copy
     lpf_ctx::Scratch &S = c->sc[per_set ? c->parity : 0];
-    hipStream_t ms = pipe ? c->stream_c : c->stream;
+    hipStream_t ms = c->stream;
     c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
     c->mask_set = per_set ? c->parity : 0;
     if (F == 0) return LPF_OK;
     const size_t hw = (size_t)c->H * c->W;
     if ((rc = reserve(c, S.label_a, (size_t)F * hw * 4))) return rc;
-    // (mode 3 contract: the mask tensor is complete when this call is made -- the side stream does not wait for the
-    //  caller's stream, or the pack could not overlap the streaming kernel already queued there)
-    if (pipe && S.k1_recorded) LPF_HIP(c, hipStreamWaitEvent(ms, S.k1_done, 0));   // the set's previous K1 still reads its label image
     const T *d_masks = masks;
     if (M > 0 && !on_device) {
         const size_t bytes = (size_t)F * M * hw * sizeof(T);
@@ -540,12 +648,12 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         c->mask_F = F; c->mask_M = M;
         return LPF_OK;
     }
-    if (M > 0 && erode_iters == 0 && !c->pipelined && on_device != 1) {
+    if (M > 0 && erode_iters == 0 && !c->fused && on_device != 1) {
         // serial mode, nothing to erode, and the masks stay where they are (our staging buffer, or lent by the caller):
         // packing is left to the run -- a small launch does without it
         c->lazy.valid = true; c->lazy.p = d_masks; c->lazy.f32 = sizeof(T) == 4; c->lazy.mode = mode;
         S.label_bytes = lb;
-        if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));
+        if (!on_device) LPF_HIP(c, host_wait(c));
         c->mask_F = F; c->mask_M = M;
         return LPF_OK;
     }
@@ -555,8 +663,7 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     else rc = pack_typed<T, uint32_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
     if (rc) return rc;
     S.label_bytes = lb;
-    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be reused by the caller
-    if (pipe) { LPF_HIP(c, hipEventRecord(S.mask_done, ms)); S.mask_pending = true; }
+    if (!on_device) LPF_HIP(c, host_wait(c));   // the host buffer may be reused by the caller
     S.label_cur = cur;
     c->mask_F = F; c->mask_M = M;
     return LPF_OK;
@@ -637,21 +744,20 @@ void lpf_destroy(lpf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
-    if (c->stream_c) (void)hipStreamSynchronize(c->stream_c);
     for (auto &S : c->sc) {
-        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.label_a, &S.label_b};
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.label_a, &S.label_b, &S.tab};
         for (DevBuf *b : sb) release(*b);
-        if (S.k1_done) (void)hipEventDestroy(S.k1_done);
-        if (S.tail_done) (void)hipEventDestroy(S.tail_done);
-        if (S.mask_done) (void)hipEventDestroy(S.mask_done);
     }
-    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
-    if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
-    DevBuf *all[] = {&c->mask_stage, &c->boxp, &c->boxq, &c->cand, &c->box_corners, &c->box_enabled, &c->box_frames, &c->box_aux, &c->frames, &c->segs, &c->blks, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    for (auto &B : c->bx) {
+        DevBuf *bb[] = {&B.boxp, &B.boxq, &B.cand, &B.corners, &B.enabled, &B.aux, &B.bframes, &B.stage};
+        for (DevBuf *b : bb) release(*b);
+    }
+    DevBuf *all[] = {&c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ring.ev) if (e) (void)hipEventDestroy(e);
+    if (c->ring.base) (void)hipHostFree(c->ring.base);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -663,7 +769,6 @@ int lpf_set_stream(lpf_ctx *c, void *s)
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     { int rc_ = sync_all(c); if (rc_) return rc_; }
-    if (c->cu_exclusive) return fail(c, LPF_ERR_STATE, "lpf_set_stream: the context runs an exclusive CU partition on its own stream; clear it first");
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     c->stream = (hipStream_t)s;          // NULL is the null stream itself (torch's default stream has handle 0)
     ++c->generation;
@@ -694,8 +799,6 @@ int lpf_wait_for_stream(lpf_ctx *c, void *producer)
     LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     hipError_t r = hipEventRecord(e, (hipStream_t)producer);
     if (r == hipSuccess) r = hipStreamWaitEvent(c->stream, e, 0);
-    // side streams only ever start behind an event of the main stream, except the mode-3 mask pack
-    if (r == hipSuccess && c->stream_c && c->pack_side) r = hipStreamWaitEvent(c->stream_c, e, 0);
     (void)hipEventDestroy(e);                                  // released once it has completed
     if (r != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_wait_for_stream: %s", hipGetErrorString(r));
     return LPF_OK;
@@ -707,17 +810,13 @@ int lpf_release_to_stream(lpf_ctx *c, void *consumer)
     if (use_device(c)) return LPF_ERR_HIP;
     if (c->capturing) return fail(c, LPF_ERR_STATE, "lpf_release_to_stream inside graph capture");
     { int rc_ = flush_pending(c); if (rc_) return rc_; }
-    hipStream_t src[3] = {c->stream, c->stream_b, c->stream_c};
-    for (int i = 0; i < 3; ++i) {
-        if (i > 0 && !src[i]) continue;
-        if (src[i] == (hipStream_t)consumer) continue;
-        hipEvent_t e;
-        LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        hipError_t r = hipEventRecord(e, src[i]);
-        if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)consumer, e, 0);
-        (void)hipEventDestroy(e);
-        if (r != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_release_to_stream: %s", hipGetErrorString(r));
-    }
+    if (c->stream == (hipStream_t)consumer) return LPF_OK;
+    hipEvent_t e;
+    LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, c->stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)consumer, e, 0);
+    (void)hipEventDestroy(e);
+    if (r != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_release_to_stream: %s", hipGetErrorString(r));
     return LPF_OK;
 }
 
@@ -728,6 +827,10 @@ int lpf_sync(lpf_ctx *c)
     return sync_all(c);
 }
 
+#ifdef LPF_LAB
+// Lab builds only (liblpf_lab.so: tools/ and the forced-geometry fuzz tests): override the launch geometry a run would pick
+// by its size.  0 = by launch size, 1 = small with the wide tail, 2 = large, 3 = large with the segment prefixes taken from
+// the scan kernel, 4 = small with the narrow tail.  Results do not depend on it.
 int lpf_set_geometry(lpf_ctx *c, int mode)
 {
     if (!c) return LPF_ERR_ARG;
@@ -736,80 +839,26 @@ int lpf_set_geometry(lpf_ctx *c, int mode)
     ++c->generation;
     return LPF_OK;
 }
-
-// stream_b / stream_c (re)created as the partition says; called with every stream idle
-static int make_side_streams(lpf_ctx *c)
-{
-    if (c->stream_b) { (void)hipStreamDestroy(c->stream_b); c->stream_b = nullptr; }
-    if (c->stream_c) { (void)hipStreamDestroy(c->stream_c); c->stream_c = nullptr; }
-    if (c->tail_cus > 0) {
-        // Bit i of a queue's CU mask: consecutive bits go round the XCDs first (measured with tools/cumask_probe:
-        // the low 8k bits are k CUs on each of the 8 XCDs), so "the low tail_cus bits" is an even slice of every XCD.
-        hipDeviceProp_t prop;
-        LPF_HIP(c, hipGetDeviceProperties(&prop, c->device));
-        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-        if (c->tail_cus >= ncu) return fail(c, LPF_ERR_ARG, "cu partition: %d of %d CUs for the side streams leaves none", c->tail_cus, ncu);
-        std::vector<uint32_t> side((size_t)words, 0u), rest((size_t)words, 0u);
-        for (int i = 0; i < ncu; ++i) (i < c->tail_cus ? side : rest)[(size_t)i / 32] |= 1u << (i % 32);
-        LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream_b, (uint32_t)words, side.data()));
-        LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream_c, (uint32_t)words, side.data()));
-        if (c->cu_exclusive) {
-            if (!c->own_stream) return fail(c, LPF_ERR_STATE, "an exclusive CU partition needs the context's own stream (lpf_set_stream was given the caller's)");
-            (void)hipStreamDestroy(c->stream);
-            c->stream = nullptr;
-            LPF_HIP(c, hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, rest.data()));
-        }
-    } else {
-        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
-    }
-    return LPF_OK;
-}
+#endif
 
 int lpf_set_pipelined(lpf_ctx *c, int on)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (on < 0 || on > 4) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 1 tail kernels overlap the next run, 2 the tail rides in the next run's launch, "
-                                                      "3 = 1 + mask packing on a side stream, 4 = 2 + the mask pack rides as well)", on);
+    if (on == 1 || on == 3)
+        return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: modes 1 and 3 (tail kernels / mask pack on side streams) were removed in ABI 5 -- "
+                                    "they measured slower than 2 and 4 on every workload (DESIGN.md section 8); use 2 or 4");
+    if (on != 0 && on != 2 && on != 4) return fail(c, LPF_ERR_ARG, "lpf_set_pipelined: mode %d (0 off, 2 the tail rides in the next run's launch, "
+                                                                   "4 = 2 + the mask pack rides as well)", on);
     int rc = sync_all(c);
     if (rc) return rc;
     if ((rc = ensure_packed(c))) return rc;
-    const bool streams = on == 1 || on == 3;
-    if (streams && !c->stream_b && (rc = make_side_streams(c))) return rc;
-    for (auto &S : c->sc) {
-        if (streams && !S.k1_done) {
-            LPF_HIP(c, hipEventCreateWithFlags(&S.k1_done, hipEventDisableTiming));
-            LPF_HIP(c, hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
-            LPF_HIP(c, hipEventCreateWithFlags(&S.mask_done, hipEventDisableTiming));
-        }
-    }
-    c->pipelined = on != 0;
-    c->fused = on == 2 || on == 4;
+    if ((rc = pack_ride_now(c))) return rc;                // lent masks that were waiting for a run: packed now, where the next run looks
+    c->fused = on != 0;
     c->defer = on == 4;
-    c->ride.valid = false;
-    c->pack_side = on == 3;
     c->parity = 0;
+    if (c->mask_F && c->mask_set != 0) { c->mask_F = 0; c->mask_M = 0; }     // label images rotate with the sets: set the masks again
     ++c->generation;
-    return LPF_OK;
-}
-
-int lpf_set_cu_partition(lpf_ctx *c, int side_cus, int exclusive)
-{
-    if (!c) return LPF_ERR_ARG;
-    if (use_device(c)) return LPF_ERR_HIP;
-    if (side_cus < 0 || (side_cus & 7)) return fail(c, LPF_ERR_ARG, "lpf_set_cu_partition: side_cus=%d (0 = none, else a multiple of 8: the same share of every XCD)", side_cus);
-    int rc = sync_all(c);
-    if (rc) return rc;
-    if (c->cu_exclusive && c->own_stream && !(side_cus > 0 && exclusive)) {      // back to an unmasked main stream
-        (void)hipStreamDestroy(c->stream);
-        c->stream = nullptr;
-        LPF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    }
-    c->tail_cus = side_cus;
-    c->cu_exclusive = side_cus > 0 && exclusive != 0;
-    ++c->generation;
-    if (c->stream_b || c->cu_exclusive) return make_side_streams(c);
     return LPF_OK;
 }
 
@@ -818,14 +867,16 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!c) return LPF_ERR_ARG;
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
-    // pipelined modes: the tail of a run already queued / still owed counts boxes with the OLD camera's candidate grid
-    if (!c->capturing && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending)) {
+    // pipelined modes: a run still owed projects / counts boxes with the OLD camera (its candidate grid, its box job)
+    if (!c->capturing && (anything_owed(c) || c->bx[c->box_cur].job_valid)) {
         if (use_device(c)) return LPF_ERR_HIP;
         int rc_ = sync_all(c);
         if (rc_) return rc_;
     }
-    if (W != c->W || H != c->H) { c->mask_F = 0; c->mask_M = 0; c->lazy.valid = false; c->box_F = 0; c->box_off.clear(); }   // label images and the
-                                                                       // candidate grid are per W x H: set masks / boxes again
+    if (W != c->W || H != c->H) {            // label images and the candidate grid are per W x H: set masks / boxes again
+        c->mask_F = 0; c->mask_M = 0; c->lazy.valid = false; c->ride.valid = false;
+        for (auto &B : c->bx) { B.F = 0; B.box_off.clear(); B.job_valid = false; }
+    }
     memcpy(c->T, T, sizeof c->T);          // row 3 of the 4x4 is never used by the reference either (V3:567 [:, :3])
     memcpy(c->K, K, sizeof c->K);
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
@@ -854,14 +905,14 @@ int lpf_set_label_image(lpf_ctx *c, const uint32_t *label, int F, int M, int on_
     if (F < 0 || M < 0 || M > LPF_MAX_MASKS || (F > 0 && !label)) return fail(c, LPF_ERR_ARG, "set_label_image: F=%d M=%d", F, M);
     int rc;
     if ((rc = sync_all(c))) return rc;
-    lpf_ctx::Scratch &S = c->sc[c->pipelined ? c->parity : 0];
+    lpf_ctx::Scratch &S = c->sc[c->fused ? c->parity : 0];
     c->mask_F = 0; c->mask_M = 0; S.label_cur = nullptr; c->lazy.valid = false;
-    c->mask_set = c->pipelined ? c->parity : 0;
+    c->mask_set = c->fused ? c->parity : 0;
     if (F == 0) return LPF_OK;
     const size_t bytes = (size_t)F * c->H * c->W * 4;
     if ((rc = reserve(c, S.label_a, bytes))) return rc;
     LPF_HIP(c, hipMemcpyAsync(S.label_a.p, label, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, host_wait(c));
     S.label_cur = S.label_a.p;
     S.label_bytes = 4;
     c->mask_F = F; c->mask_M = M;
@@ -880,18 +931,18 @@ int lpf_get_label_image(lpf_ctx *c, uint32_t *out, int on_device)
     const size_t npix = (size_t)c->mask_F * c->H * c->W;
     if (S.label_bytes == 4) {
         LPF_HIP(c, hipMemcpyAsync(out, S.label_cur, npix * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, host_wait(c));
         return LPF_OK;
     }
     // narrow label images (M <= 16) are widened on the host: this entry point exists for tests
     std::vector<uint8_t> raw(npix * (size_t)S.label_bytes);
     LPF_HIP(c, hipMemcpyAsync(raw.data(), S.label_cur, raw.size(), hipMemcpyDeviceToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, host_wait(c));
     std::vector<uint32_t> wide(npix);
     for (size_t i = 0; i < npix; ++i)
         wide[i] = S.label_bytes == 1 ? (uint32_t)raw[i] : (uint32_t)reinterpret_cast<const uint16_t *>(raw.data())[i];
     LPF_HIP(c, hipMemcpyAsync(out, wide.data(), npix * 4, on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, host_wait(c));
     return LPF_OK;
 }
 
@@ -902,61 +953,14 @@ int lpf_set_boxes(lpf_ctx *c, const double *corners, const int32_t *box_off, int
 
 int lpf_set_boxes_ex(lpf_ctx *c, const double *corners, int on_device, const int32_t *box_off, int F, int oriented)
 {
-    if (!c) return LPF_ERR_ARG;
-    if (use_device(c)) return LPF_ERR_HIP;
-    if (F == 0) { c->box_F = 0; c->box_off.clear(); return LPF_OK; }
-    int rc;
-    if ((rc = box_layout(c, box_off, F, oriented, "set_boxes"))) { c->box_F = 0; return rc; }
-    const int Btot = box_off[F];
-    if (Btot > 0 && !corners) { c->box_F = 0; return fail(c, LPF_ERR_ARG, "set_boxes: corners is NULL"); }
-    c->have_enabled = false;
-    if (Btot > 0) {
-        LPF_HIP(c, hipMemcpyAsync(c->box_corners.p, corners, (size_t)Btot * 24 * sizeof(double),
-                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-        if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));      // the caller's host buffer is free on return
-    }
-    return launch_box_setup(c);
+    return set_boxes_impl(c, corners, on_device, box_off, F, oriented, false, nullptr, 0, nullptr, nullptr, nullptr, nullptr, "set_boxes");
 }
 
 int lpf_set_boxes_cam0(lpf_ctx *c, const double *corners_cam0, int on_device, const int32_t *box_off, int F, const double Tcv[16],
                        int filter_visible, int oriented, uint8_t *visible, double *corners_velo, double *bbox2d, int32_t *front)
 {
-    if (!c) return LPF_ERR_ARG;
-    if (use_device(c)) return LPF_ERR_HIP;
-    if (F == 0) { c->box_F = 0; c->box_off.clear(); return LPF_OK; }
-    int rc;
-    if (!Tcv) return fail(c, LPF_ERR_ARG, "set_boxes_cam0: T_cam_to_velo is NULL");
-    if ((rc = box_layout(c, box_off, F, oriented, "set_boxes_cam0"))) { c->box_F = 0; return rc; }
-    const int Btot = box_off[F];
-    if (Btot > 0 && !corners_cam0) { c->box_F = 0; return fail(c, LPF_ERR_ARG, "set_boxes_cam0: corners is NULL"); }
-    if (Btot == 0) { c->have_enabled = false; return LPF_OK; }
-    const size_t nb = (size_t)Btot;
-    // aux: {cam-0 corners (host callers), visible bytes come from box_enabled, 2D boxes, front counts}
-    const size_t o_in = 0, o_bb = o_in + nb * 192, o_fr = o_bb + nb * 32, total = o_fr + nb * 4;
-    if ((rc = reserve(c, c->box_aux, total))) return rc;
-    if ((rc = reserve(c, c->box_enabled, nb))) return rc;
-    char *aux = (char *)c->box_aux.p;
-    const double *d_in = corners_cam0;
-    if (!on_device) {
-        LPF_HIP(c, hipMemcpyAsync(aux + o_in, corners_cam0, nb * 192, hipMemcpyHostToDevice, c->stream));
-        d_in = (const double *)(aux + o_in);
-    }
-    LpfBoxPrep A;
-    memcpy(A.Tcv, Tcv, sizeof A.Tcv);
-    memcpy(A.K, c->K, sizeof A.K);
-    A.W = c->W; A.H = c->H;
-    hipLaunchKernelGGL(lpf_box_prep_kernel, dim3((unsigned)((nb * 8 + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream, A, d_in,
-                       Btot, (uint8_t *)c->box_enabled.p, (double *)c->box_corners.p, (double *)(aux + o_bb), (int *)(aux + o_fr));
-    LPF_HIP(c, hipGetLastError());
-    c->have_enabled = filter_visible != 0;
-    if ((rc = launch_box_setup(c))) return rc;
-    const hipMemcpyKind back = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (visible) LPF_HIP(c, hipMemcpyAsync(visible, c->box_enabled.p, nb, back, c->stream));
-    if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, c->box_corners.p, nb * 192, back, c->stream));
-    if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, aux + o_bb, nb * 32, back, c->stream));
-    if (front) LPF_HIP(c, hipMemcpyAsync(front, aux + o_fr, nb * 4, back, c->stream));
-    if (!on_device) LPF_HIP(c, hipStreamSynchronize(c->stream));          // host buffers (in and out) are the caller's again
-    return LPF_OK;
+    return set_boxes_impl(c, corners_cam0, on_device, box_off, F, oriented, true, Tcv, filter_visible, visible, corners_velo, bbox2d, front,
+                          "set_boxes_cam0");
 }
 
 int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F, int pts_on_device, const lpf_outputs *out)
@@ -972,11 +976,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     }
     const int64_t Ntot = frame_off[F];
     if (Ntot > 0 && !pts) return fail(c, LPF_ERR_ARG, "run: pts is NULL");
+    lpf_ctx::BoxSet &BX = c->bx[c->box_cur];
     if (c->mask_F != 0 && c->mask_F != F) return fail(c, LPF_ERR_STATE, "masks were set for %d frames, run has %d", c->mask_F, F);
-    if (c->box_F != 0 && c->box_F != F) return fail(c, LPF_ERR_STATE, "boxes were set for %d frames, run has %d", c->box_F, F);
+    if (BX.F != 0 && BX.F != F) return fail(c, LPF_ERR_STATE, "boxes were set for %d frames, run has %d", BX.F, F);
     if (out->inst_idx && out->inst_cap <= 0) return fail(c, LPF_ERR_ARG, "run: inst_idx given with inst_cap=%lld", (long long)out->inst_cap);
+    if ((out->uv_valid || out->label_valid) && !out->valid_idx)
+        return fail(c, LPF_ERR_ARG, "run: uv_valid / label_valid need valid_idx as well (they share its order)");
     const int M = c->mask_F ? c->mask_M : 0;
-    const int Btot = c->box_F ? c->box_off[F] : 0;
+    const int Btot = BX.F ? BX.box_off[F] : 0;
     const bool host_io = !out->on_device;
     int rc;
 
@@ -984,10 +991,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     //      groups of 64 segments are the second level of the counters ------------------------------------------------
     const bool small = c->geometry == 1 || c->geometry == 4 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
     const int64_t seg_pts = small ? LPF_SEG_SMALL : LPF_SEG_QUANTUM;
-    if (c->box_F && c->cand_dirty && (rc = launch_box_setup(c))) return rc;     // the camera changed since the boxes were set
     c->h_frames.resize(F);
     int nseg_total = 0, ngrp_total = 0, max_ngrp = 0;
-    int64_t max_n = 0;
     for (int f = 0; f < F; ++f) {
         LpfFrame &fr = c->h_frames[f];
         fr.pt_off = frame_off[f];
@@ -995,24 +1000,22 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.seg_off = nseg_total;
         fr.nseg = (int)((fr.N + seg_pts - 1) / seg_pts);
         nseg_total += fr.nseg;
-        fr.box_off = c->box_F ? c->box_off[f] : 0;
-        fr.B = c->box_F ? c->box_off[f + 1] - c->box_off[f] : 0;
+        fr.box_off = BX.F ? BX.box_off[f] : 0;
+        fr.B = BX.F ? BX.box_off[f + 1] - BX.box_off[f] : 0;
         fr.inst_base = (long long)f * out->inst_cap;
         fr.pad = f;
-        fr.cand_off = c->box_F ? c->cand_off[f] : 0;
+        fr.cand_off = BX.F ? BX.cand_off[f] : 0;
         fr.cand_words = (fr.B + 63) / 64;
         fr.grp_off = ngrp_total;
         fr.pad3 = 0; fr.pad4 = 0;
         const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
         ngrp_total += ngrp;
         if (ngrp > max_ngrp) max_ngrp = ngrp;
-        if (fr.N > max_n) max_n = fr.N;
     }
     const int nseg_cap = nseg_total > 0 ? nseg_total : 1, ngrp_cap = ngrp_total > 0 ? ngrp_total : 1;
     // tail blocks: four consecutive segments of one frame each (an empty frame still gets one, to write its summary);
     // the list blocks, then -- when boxes are to be counted -- as many box-count blocks
-    const int M_ = c->mask_F ? c->mask_M : 0;
-    const bool count_boxes = M_ > 0 && c->box_F && c->box_off[F] > 0;
+    const bool count_boxes = M > 0 && Btot > 0;
     int nblk = 0;
     for (int f = 0; f < F; ++f) {
         const int nb = c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
@@ -1023,24 +1026,42 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // (16.7 M points) take their prefixes from the scan kernel instead
     const bool pre_scan = max_ngrp > 64 || c->geometry == 3;
 
-    // pipelined device runs rotate through the scratch sets (2, 3 or 4 by mode); everything else uses set 0 with every stream idle
-    const bool pipe_any = c->pipelined && !host_io && pts_on_device && !c->capturing;
-    const bool fused = pipe_any && c->fused;               // the tail rides in the next run's launch (three scratch sets; four in mode 4)
-    const bool pipe = pipe_any && !c->fused;               // the tail runs on a second stream (two scratch sets)
-    if (!pipe_any && (c->pend_k1.valid || c->pend_tail.valid || c->pend_fin.valid || c->sc[0].tail_pending || c->sc[1].tail_pending) && (rc = sync_all(c)))
-        return rc;                                         // set 0 is used with every stream idle and nothing owed
-    lpf_ctx::Scratch &S = c->sc[pipe_any ? c->parity : 0];
-    hipStream_t tail_stream = pipe ? c->stream_b : c->stream;
-    if ((rc = reserve(c, c->frames, (size_t)F * sizeof(LpfFrame)))) return rc;
+    // software-pipelined device runs rotate through the scratch sets (3 in mode 2, 4 in mode 4); everything else uses set 0 with
+    // nothing owed
+    const bool fused = c->fused && !host_io && pts_on_device && !c->capturing;   // one launch per run, the tail rides in the next
+    if (!fused && anything_owed(c) && (rc = sync_all(c))) return rc;
+    lpf_ctx::Scratch &S = c->sc[fused ? c->parity : 0];
     if ((rc = reserve(c, S.vbal, rows * 8))) return rc;
     if ((rc = reserve(c, S.mbal, rows * 8))) return rc;
     if ((rc = reserve(c, S.seg_tab, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4), true))) return rc;
     if ((rc = reserve(c, S.grp_tab, (size_t)LPF_TAB_GROUPS * ngrp_cap * sizeof(uint4), true))) return rc;
     if ((rc = reserve(c, S.frm_tab, (size_t)F * LPF_FRM_SHARDS * LPF_TAB_GROUPS * sizeof(uint4), true))) return rc;
     if (pre_scan && (rc = reserve(c, S.seg_pre, (size_t)LPF_TAB_GROUPS * nseg_cap * sizeof(uint4)))) return rc;
-    if (F > 1 && (rc = reserve(c, c->segs, (size_t)nseg_cap * sizeof(LpfFrame)))) return rc;
-    if ((rc = reserve(c, c->blks, (size_t)nblk * sizeof(int2)))) return rc;
     if ((rc = reserve(c, S.cnt, (size_t)(M > 0 ? M : 1) * (Btot > 0 ? Btot : 1) * 4, true))) return rc;
+
+    // ---- geometry tables of the run, in its own scratch set: the frame records, the owning frame's record per segment, the
+    //      tail block table.  A single frame needs none of them (record by value, block table computed).  They only change
+    //      when the batch shape does, and then travel through the pinned ring: no wait, no drain ---------------------------
+    const bool have_tab = S.tab_frames.size() == (size_t)F && memcmp(S.tab_frames.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) == 0;
+    if (F > 1 && !have_tab) {
+        const size_t b_frames = (size_t)F * sizeof(LpfFrame), b_segs = (size_t)nseg_total * sizeof(LpfFrame), b_blks = (size_t)nblk * sizeof(int2);
+        if ((rc = reserve(c, S.tab, b_frames + b_segs + b_blks))) return rc;
+        c->h_tab.resize(b_frames + b_segs + b_blks);
+        memcpy(c->h_tab.data(), c->h_frames.data(), b_frames);
+        LpfFrame *hs = reinterpret_cast<LpfFrame *>(c->h_tab.data() + b_frames);
+        int2 *hb = reinterpret_cast<int2 *>(c->h_tab.data() + b_frames + b_segs);
+        for (int f = 0; f < F; ++f) {
+            const LpfFrame &fr = c->h_frames[f];
+            for (int sg = 0; sg < fr.nseg; ++sg) hs[(size_t)fr.seg_off + sg] = fr;
+            if (fr.nseg == 0) *hb++ = make_int2(fr.seg_off, f << 3);
+            for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES) *hb++ = make_int2(fr.seg_off + sg, (f << 3) | std::min(LPF_LISTS_WAVES, fr.nseg - sg));
+        }
+        S.tab_frames.clear();                              // (nothing valid if the upload fails half way)
+        if ((rc = upload(c, S.tab.p, c->h_tab.data(), c->h_tab.size()))) return rc;
+        S.tab_frames = c->h_frames;
+        S.o_segs = b_frames; S.o_blks = b_frames + b_segs;
+        ++c->generation;                  // graphs captured for another geometry read these tables
+    }
 
     LpfParams P;
     memset(&P, 0, sizeof P);
@@ -1048,8 +1069,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     memcpy(P.K, c->K, sizeof P.K);
     P.dmin = c->dmin; P.dmax = c->dmax; P.W = c->W; P.H = c->H;
     P.F = F; P.M = M; P.seg_pts = (int)seg_pts; P.nseg_total = nseg_total; P.nseg_cap = nseg_cap; P.ngrp_cap = ngrp_cap;
-    P.oriented = c->oriented; P.inst_cap = out->inst_cap;
-    P.frames = (const LpfFrame *)c->frames.p; P.frame0 = c->h_frames[0];
+    P.oriented = BX.oriented; P.inst_cap = out->inst_cap;
+    P.frame0 = c->h_frames[0];
+    if (F > 1) {
+        P.frames = (const LpfFrame *)S.tab.p;
+        P.segs = (const LpfFrame *)((const char *)S.tab.p + S.o_segs);
+        P.blks = (const int2 *)((const char *)S.tab.p + S.o_blks);
+    }
     // lent masks of a pipelined context (lpf_ctx::Ride): a small fused launch reads them directly, a large one in mode 4 carries
     // their pack, anything else (mode 2, float masks, a host-memory run) packs them now
     // (directly: M gathers per valid point against M reads per pixel for the pack -- it pays while a frame has fewer points than
@@ -1060,22 +1086,22 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
     if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
-    const bool direct = M > 0 && c->lazy.valid && small && sparse_frames && !pipe_any;
+    const bool direct = M > 0 && c->lazy.valid && small && sparse_frames && !fused;
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
     // The label image lives in the scratch set that was current when the masks were set.  A pipelined run must find it in its
-    // own set (the sets rotate: masks are set before every run); any other run has every stream idle and reads it where it is.
+    // own set (the sets rotate: masks are set before every run); any other run has nothing owed and reads it where it is.
     const lpf_ctx::Scratch &SM = c->sc[c->mask_set];
-    if (M > 0 && pipe_any && !direct && c->mask_set != c->parity)
+    if (M > 0 && fused && !direct && c->mask_set != c->parity)
         return fail(c, LPF_ERR_STATE, "the masks were set for another scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.label_img = (M > 0) ? (direct ? c->lazy.p : direct_fused ? c->ride.masks : SM.label_cur) : nullptr;
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
-    P.boxp = (const double *)c->boxp.p; P.boxq = (const float *)c->boxq.p;
-    P.cand = (const unsigned long long *)c->cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
+    P.boxp = (const double *)BX.boxp.p; P.boxq = (const float *)BX.boxq.p;
+    P.cand = (const unsigned long long *)BX.cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
     P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
-    P.segs = (const LpfFrame *)c->segs.p; P.cnt = (unsigned *)S.cnt.p;
-    P.blks = (const int2 *)c->blks.p; P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
+    P.cnt = (unsigned *)S.cnt.p;
+    P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -1095,8 +1121,6 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             P.field = (decltype(P.field))out->member;                             \
         }                                                                         \
     }
-    if ((out->uv_valid || out->label_valid) && !out->valid_idx)
-        return fail(c, LPF_ERR_ARG, "run: uv_valid / label_valid need valid_idx as well (they share its order)");
     LPF_OUTBUF(uv, uv, st_uv, n * 8)
     LPF_OUTBUF(label_bits, label_bits, st_label, n * 4)
     // the compact copies are gathered from the dense arrays: keep those in internal buffers when the caller skips them
@@ -1123,33 +1147,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         P.mlist = (float4 *)S.mlist.p;
     }
 
-    // The frame table only changes when the batch geometry does; upload it then (and wait, the
-    // source is pageable host memory that the next call rewrites).
-    if (c->h_frames_dev.size() != c->h_frames.size() ||
-        memcmp(c->h_frames_dev.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) != 0) {
-        if ((rc = sync_all(c))) return rc;                 // a pending tail may still read the old tables
-        LPF_HIP(c, hipMemcpyAsync(c->frames.p, c->h_frames.data(), (size_t)F * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
-        if (F > 1) {                                      // per-segment copy of the owning frame's record
-            c->h_segs.resize((size_t)nseg_total);
-            for (int f = 0; f < F; ++f)
-                for (int sg = 0; sg < c->h_frames[f].nseg; ++sg) c->h_segs[(size_t)c->h_frames[f].seg_off + sg] = c->h_frames[f];
-            if (nseg_total)
-                LPF_HIP(c, hipMemcpyAsync(c->segs.p, c->h_segs.data(), (size_t)nseg_total * sizeof(LpfFrame), hipMemcpyHostToDevice, c->stream));
-        }
-        c->h_blks.clear();
-        for (int f = 0; f < F; ++f) {
-            const LpfFrame &fr = c->h_frames[f];
-            if (fr.nseg == 0) c->h_blks.push_back(make_int2(fr.seg_off, f << 3));
-            for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES)
-                c->h_blks.push_back(make_int2(fr.seg_off + sg, (f << 3) | std::min(LPF_LISTS_WAVES, fr.nseg - sg)));
-        }
-        LPF_HIP(c, hipMemcpyAsync(c->blks.p, c->h_blks.data(), c->h_blks.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
-        c->h_frames_dev = c->h_frames;
-        ++c->generation;                  // graphs captured for another geometry read these tables
-    }
-    if (pipe && S.tail_pending) LPF_HIP(c, hipStreamWaitEvent(c->stream, S.tail_done, 0));   // this set's previous tail
-    if (pipe && S.mask_pending) { LPF_HIP(c, hipStreamWaitEvent(c->stream, S.mask_done, 0)); S.mask_pending = false; }
+    // the box tables this run's tail counts into: rebuilt if the camera changed since they were made
+    if (BX.F && c->cand_dirty && !BX.job_valid) box_rebuild_job(BX);
+    c->cand_dirty = false;
+    BX.used = true;
+    BX.last_ref = c->run_seq++;
+
     // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
     P.tile_pts = small ? 512 : 1024;
     // the fused launch shares the chip with the previous run's tail blocks: 2048-point tiles keep twice the loads in flight
@@ -1177,13 +1180,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     }
     if (fused) {
         // ---- one launch (lpf_step_t): K1 tiles, the tail blocks of the run before dealt out among them, the summaries of the
-        //      run before that.  Mode 2: the tiles are this run's.  Mode 4: this run's MASK PACK rides as well (lent uint8 masks),
-        //      the tiles are the previous run's -- everything one launch later, nothing left on the stream between two steps.
+        //      run before that, and the box job of THIS run (its tables are read by this run's tail, one or two launches on).
+        //      Mode 2: the tiles are this run's.  Mode 4: this run's MASK PACK rides as well (lent uint8 masks), the tiles are
+        //      the previous run's -- everything one launch later, nothing left on the stream between two steps.
         lpf_ctx::Pending cur;
         cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
         cur.direct = direct_fused; cur.dsel = c->ride.f32 ? c->ride.mode : 0;
         const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur, Q = c->pend_tail, R = c->pend_fin;
-        if ((rc = launch_step(c, KK, Q, R, ride_pack, lb, e1))) return rc;
+        if ((rc = launch_step(c, KK, Q, R, ride_pack, lb, &BX, e1))) return rc;
         c->pend_fin = Q;                                   // its tail has just been launched: summaries in a later launch
         c->pend_tail = KK;
         if (c->defer) c->pend_k1 = cur;
@@ -1191,6 +1195,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         c->parity = (c->parity + 1) % (c->defer ? 4 : 3);
         return LPF_OK;
     }
+    if ((rc = launch_box_job(c, BX))) return rc;           // (serial mode: only a rebuild after a camera change is still waiting here)
     if (nk1 > 0) {
         const dim3 g1((unsigned)nk1);
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
@@ -1206,33 +1211,23 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_HIP(c, hipGetLastError());
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
     }
-    if (pipe) {                                            // hand over to the second stream
-        LPF_HIP(c, hipEventRecord(S.k1_done, c->stream));
-        S.k1_recorded = true;
-        LPF_HIP(c, hipStreamWaitEvent(tail_stream, S.k1_done, 0));
-    }
     // ---- the tail: lists and box counts in one launch (a wave per segment each, side by side), then the per-frame summaries ----
     if (pre_scan && nseg_total > 0) {
-        hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
+        hipLaunchKernelGGL(lpf_scan_segments, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
         LPF_HIP(c, hipGetLastError());
     }
     if (ntail > 0) {
         if (small && count_boxes && c->geometry != 4 && (nblk <= LPF_WIDE_BELOW || c->geometry == 1)) {   // a frame or a few, dense real segments: the box-count blocks share their chunks over 16 waves
-            if (pre_scan) hipLaunchKernelGGL((lpf_tail_wide_t<true>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
-            else hipLaunchKernelGGL((lpf_tail_wide_t<false>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, tail_stream, P);
+            if (pre_scan) hipLaunchKernelGGL((lpf_tail_wide_t<true>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, c->stream, P);
+            else hipLaunchKernelGGL((lpf_tail_wide_t<false>), dim3((unsigned)ntail), dim3(64 * LPF_WIDE_WAVES), 0, c->stream, P);
         } else {
-            launch_tail(tail_stream, P, ntail, pre_scan);
+            launch_tail(c->stream, P, ntail, pre_scan);
         }
         LPF_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(lpf_finalize, dim3(F), dim3(LPF_BLOCK), 0, tail_stream, P);
+    hipLaunchKernelGGL(lpf_finalize, dim3(F), dim3(LPF_BLOCK), 0, c->stream, P);
     LPF_HIP(c, hipGetLastError());
 
-    if (pipe) {
-        LPF_HIP(c, hipEventRecord(S.tail_done, tail_stream));
-        S.tail_pending = true;
-        c->parity ^= 1;
-    }
     if (host_io) {
 #define LPF_D2H(member, field, bytes) \
     if (out->member && (bytes)) LPF_HIP(c, hipMemcpyAsync(out->member, P.field, (bytes), hipMemcpyDeviceToHost, c->stream));
@@ -1245,7 +1240,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         // lists: fetch the summary first, then only the filled part of each list
         std::vector<lpf_frame_summary> hs((size_t)F);
         LPF_HIP(c, hipMemcpyAsync(hs.data(), P.summary, (size_t)F * sizeof(lpf_frame_summary), hipMemcpyDeviceToHost, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, host_wait(c));
         for (int f = 0; f < F; ++f) {
             const size_t nv = (size_t)hs[f].n_valid;
             if (out->valid_idx && nv)
@@ -1265,7 +1260,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         }
         if (out->summary) memcpy(out->summary, hs.data(), (size_t)F * sizeof(lpf_frame_summary));
 #undef LPF_D2H
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, host_wait(c));
     }
     return LPF_OK;
 }
@@ -1279,8 +1274,7 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
         return fail(c, LPF_ERR_ARG, "points_in_boxes: k=%lld B=%d stride=%d", (long long)k, B, stride);
     if (k == 0 || B == 0) return LPF_OK;
     std::vector<double> bp((size_t)B * 16);
-    std::vector<float> bq(8);
-    for (int b = 0; b < B; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16, bq.data());
+    for (int b = 0; b < B; ++b) box_params(corners + (size_t)b * 24, oriented, bp.data() + (size_t)b * 16);
     int rc;
     if ((rc = reserve(c, c->pib_box, bp.size() * 8))) return rc;
     LPF_HIP(c, hipMemcpyAsync(c->pib_box.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -1296,7 +1290,7 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
                        d_pts, (long long)k, stride, (const double *)c->pib_box.p, B, oriented ? 1 : 0, d_out);
     LPF_HIP(c, hipGetLastError());
     if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));           // bp is a local
+    LPF_HIP(c, host_wait(c));           // bp is a local
     return LPF_OK;
 }
 
@@ -1333,11 +1327,11 @@ int lpf_depth_image(lpf_ctx *c, const float *pts, int64_t N, int on_device, doub
         LPF_HIP(c, hipMemcpyAsync(depth_img, dD, hw * 8, hipMemcpyDeviceToHost, c->stream));
         if (winner) {
             LPF_HIP(c, hipMemcpyAsync(winner, dW, hw * 4, hipMemcpyDeviceToHost, c->stream));
-            LPF_HIP(c, hipStreamSynchronize(c->stream));
+            LPF_HIP(c, host_wait(c));
             for (size_t i = 0; i < hw; ++i) winner[i] -= 1;          // stored as index + 1, 0 = none
             return LPF_OK;
         }
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, host_wait(c));
     } else if (winner) {
         return fail(c, LPF_ERR_ARG, "depth_image: the winner image is only returned to host callers");
     }
@@ -1370,7 +1364,7 @@ int lpf_prepare_boxes(lpf_ctx *c, const double *corners_cam0, int nbox, const do
     if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, base + o_cv, nb * 192, hipMemcpyDeviceToHost, c->stream));
     if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, base + o_bb, nb * 32, hipMemcpyDeviceToHost, c->stream));
     if (front) LPF_HIP(c, hipMemcpyAsync(front, base + o_fr, nb * 4, hipMemcpyDeviceToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, host_wait(c));
     return LPF_OK;
 }
 
@@ -1378,7 +1372,7 @@ int lpf_graph_begin(lpf_ctx *c)
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    if (c->pipelined) return fail(c, LPF_ERR_STATE, "graph capture needs pipelining off");
+    if (c->fused) return fail(c, LPF_ERR_STATE, "graph capture needs pipelining off");
     if (c->capturing) return fail(c, LPF_ERR_STATE, "already capturing");
     int rc = sync_all(c);
     if (rc) return rc;
@@ -1425,6 +1419,14 @@ void lpf_graph_destroy(lpf_graph *g)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
+}
+
+int lpf_get_stats(lpf_ctx *c, int64_t *out, int n, int reset)
+{
+    if (!c || (n > 0 && !out) || n < 0) return LPF_ERR_ARG;
+    for (int i = 0; i < n; ++i) out[i] = i < 8 ? (int64_t)c->stats[i] : 0;
+    if (reset) for (long long &v : c->stats) v = 0;
+    return LPF_OK;
 }
 
 int lpf_profile_enable(lpf_ctx *c, int on)
@@ -1474,7 +1476,7 @@ int lpf_allreduce_metrics(lpf_ctx *c, int64_t *vec, int n, int op, void *rccl_co
     const int nrc = p_allreduce(c->coll.p, c->coll.p, (size_t)n, 4 /* ncclInt64 */, red[op], rccl_comm, c->stream);
     if (nrc != 0) return fail(c, LPF_ERR_HIP, "ncclAllReduce failed: %s", p_errstr ? p_errstr(nrc) : "?");
     LPF_HIP(c, hipMemcpyAsync(vec, c->coll.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    LPF_HIP(c, hipStreamSynchronize(c->stream));          // blocks, with no timeout, until every rank has joined the collective
+    LPF_HIP(c, host_wait(c));          // blocks, with no timeout, until every rank has joined the collective
     return LPF_OK;
 }
 
@@ -1490,10 +1492,9 @@ int lpf_profile_overhead(lpf_ctx *c, double *empty_bracket_ms)
     LPF_HIP(c, hipEventCreate(&e1));
     float v[33];
     for (int i = 0; i < 33; ++i) {
-        LPF_HIP(c, hipMemsetAsync(c->frames.p ? c->frames.p : c->sc[0].seg_tab.p, 0, 0, c->stream));   // no-op; keeps the call pattern uniform
         LPF_HIP(c, hipEventRecord(e0, c->stream));
         LPF_HIP(c, hipEventRecord(e1, c->stream));
-        LPF_HIP(c, hipStreamSynchronize(c->stream));
+        LPF_HIP(c, host_wait(c));
         LPF_HIP(c, hipEventElapsedTime(&v[i], e0, e1));
     }
     (void)hipEventDestroy(e0);
@@ -1507,7 +1508,7 @@ int lpf_profile_read(lpf_ctx *c, double *k1_ms_sum, int64_t *k1_launches, int re
 {
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
-    LPF_HIP(c, hipStreamSynchronize(c->stream));
+    LPF_HIP(c, host_wait(c));
     double sum = 0.0;
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0.f;

@@ -695,11 +695,14 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
     if (P.valid_idx && nv) {
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
         const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        // run_v comes from counters in memory: whatever they hold, a store never leaves the frame's own N slots (with sound
+        // counters run_v + nv <= N always; see DESIGN.md section 9 for the fault this guard is the answer to)
+        const long long room = (long long)fr.N - run_v;
         if (nv > (unsigned)LPF_LIST_CAP || nv > 6u * (unsigned)nrows) {
             for (int r = 0; r < nrows; ++r) {
                 const unsigned long long rv = lpf_rl64(vb, r);                      // wave-uniform
-                if ((rv >> lane) & 1ull) {
-                    const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+                const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+                if (((rv >> lane) & 1ull) && pos < room) {
                     dst[pos] = (long long)(seg_start + r * 64 + lane);
                     if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
                     if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
@@ -708,7 +711,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
         } else {
             lpf_bits_to_list(vb, vbase, lane, lst);
             __builtin_amdgcn_wave_barrier();
-            for (unsigned e = lane; e < nv; e += 64) {
+            for (unsigned e = lane; e < nv && (long long)e < room; e += 64) {
                 const int pt = seg_start + (int)lst[e];
                 dst[e] = (long long)pt;
                 if (P.uv_valid) P.uv_valid[o + e] = P.uv[fr.pt_off + pt];
@@ -840,11 +843,14 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
     if (P.valid_idx && nv) {
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
         const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        // run_v comes from counters in memory: whatever they hold, a store never leaves the frame's own N slots (with sound
+        // counters run_v + nv <= N always; see DESIGN.md section 9 for the fault this guard is the answer to)
+        const long long room = (long long)fr.N - run_v;
         for (int r = 0; r < nrows; ++r) {
             const unsigned long long rv = lpf_rl64(vb, r);                              // wave-uniform
             if (rv == 0ull) continue;
-            if ((rv >> lane) & 1ull) {
-                const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+            const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
+            if (((rv >> lane) & 1ull) && pos < room) {
                 dst[pos] = (long long)(seg_start + r * 64 + lane);
                 if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
                 if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
@@ -1124,6 +1130,15 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
 // counted -- count their segments' masked points into the boxes.  Neither half needs anything from the other, and
 // nothing waits inside the kernel.  lpf_finalize then writes the per-frame summaries.
 // ------------------------------------------------------------------------------------
+// Tail block table: {first segment, frame << 3 | segments (0..4)} of block i.  A launch of ONE frame needs no table (and so
+// no upload when its size changes from run to run): block i takes segments 4 i .. 4 i + 3 of frame 0.
+__device__ __forceinline__ int2 lpf_tail_entry(const LpfParams &P, const int i)
+{
+    if (P.F > 1) return P.blks[i];
+    const int first = i * LPF_LISTS_WAVES;
+    return make_int2(first, max(0, min(LPF_LISTS_WAVES, P.frame0.nseg - first)));
+}
+
 struct LpfTailListsLds { unsigned short lidx[LPF_LISTS_WAVES][LPF_LIST_CAP]; };            // masked entries of a pass
 struct LpfTailCountLds {
     float4 pt[LPF_LISTS_WAVES][64];           // xyz + label of a wave's current chunk
@@ -1135,6 +1150,7 @@ struct LpfTailCountLds {
 };
 
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
+#define LPF_STEP_LDS (LPF_TAIL_LDS > sizeof(LpfBoxJobLds) ? LPF_TAIL_LDS : sizeof(LpfBoxJobLds))
 
 // one tail block: the first nblk count boxes (when there are any: the longer chain goes first), the next nblk build lists
 template <bool PRE, int STEP>
@@ -1145,7 +1161,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     const int tid = threadIdx.x, wave = lpf_wave();
     const int ncount = P.count_boxes ? P.nblk : 0;          // (the list blocks follow; none when no list is wanted)
     const bool count_role = tb < ncount;
-    const int2 ent = P.blks[count_role ? tb : tb - ncount]; // {first segment, frame << 3 | segments}
+    const int2 ent = lpf_tail_entry(P, count_role ? tb : tb - ncount);     // {first segment, frame << 3 | segments}
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
@@ -1213,7 +1229,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     const int tid = threadIdx.x, lane = lpf_lane(), wave = tid >> 6, tb = (int)blockIdx.x;
     const int ncount = P.count_boxes ? P.nblk : 0;
     const bool count_role = tb < ncount;
-    const int2 ent = P.blks[count_role ? tb : tb - ncount];
+    const int2 ent = lpf_tail_entry(P, count_role ? tb : tb - ncount);
     const int f = ent.y >> 3, nw = ent.y & 7;
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (!count_role) {
@@ -1281,12 +1297,39 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 // ------------------------------------------------------------------------------------
 struct LpfStepLayout {
     int nfin, nfin8;             // summary blocks (frames of run i-2), padded
+    int nbox, nbox8;             // box-job blocks (frames of the run whose boxes were set since the last launch), padded
     int ntail;                   // tail blocks of run i-1
     int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
     int nk1;                     // K1 tiles of run i
     int npack;                   // mask-pack blocks (mode 4: of the run whose K1 tiles the NEXT launch carries), after all K1 tiles
     int rest;                    // K1 block slots after the periods
 };
+struct LpfBoxFrame {             // per frame, host-built from the box counts
+    int box_off, B;
+    long long cand_off;          // first word of the frame's grid
+};
+struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_frame_block): a block per frame
+    const double *src;           // [Btot][8][3] corners, cam-0 frame (cam0 = 1) or velodyne frame
+    const uint8_t *enabled_in;   // velodyne-frame input: [Btot] 0 = dropped earlier by filter_visible_bboxes, or null
+    int cam0, filter_visible, oriented, F;
+    double Tcv[12];              // rows 0..2 of inv(TrVeloToCam) (cam0 = 1)
+    double T[12], K[9];          // TrVeloToRect rows 0..2, camera.K[:3,:3]
+    int W, H, cell_shift, cell_w, cell_h, nblk;      // nblk: blocks of the role (= F)
+    const LpfBoxFrame *bframes;  // [F] (F > 1)
+    LpfBoxFrame frame0;          // ... by value for one frame
+    double *boxp; float *boxq; unsigned long long *cand;
+    double *corners_keep;        // [Btot][8][3] the context's copy of the velodyne-frame corners (a camera change rebuilds from it), or null
+    uint8_t *enabled_out;        // [Btot] the context's copy of `visible` (cam0 = 1), or null
+    uint8_t *visible; double *corners_out; double *bbox2d; int32_t *front;      // optional outputs of lpf_set_boxes_cam0 (device memory)
+};
+#define LPF_BOXJOB_CAP 1024       // boxes of a frame whose rectangles are staged at a time (more: further passes)
+
+struct LpfBoxJobLds {
+    double c[32][8][3];           // velodyne-frame corners of the pass's 32 boxes
+    short rect[LPF_BOXJOB_CAP][4];   // {x0, x1, y0, y1} in cells; x0 > x1 = no cell
+};
+
+__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int f, char *s_raw);
 struct LpfPackJob {              // uint8 masks [F][M][H][W] -> label image [F][H][W] of the step's LT (lpf_pack16_block)
     const uint8_t *masks;
     void *label;
@@ -1297,11 +1340,11 @@ template <typename T, int MODE, typename LT>
 __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
                                                  const int M, const long long hw, const long long total16, const long long blk);
 
-template <int ROWS, unsigned FL, typename LT, bool PRE>
+template <int ROWS, unsigned FL, typename LT, bool PRE, bool BOXES>
 __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y,
-                                                           const LpfPackJob J)
+                                                           const LpfPackJob J, const LpfBoxJob X)
 {
-    __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
+    __shared__ __attribute__((aligned(16))) char s_raw[LPF_STEP_LDS];
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
     int b = (int)blockIdx.x;
     if (b < Y.nfin8) {                                      // ---- summaries of run i-2
@@ -1312,6 +1355,13 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         return;
     }
     b -= Y.nfin8;
+    if (b < Y.nbox8) {                                      // ---- box tables of the run that follows (a block per frame): they are read
+        if constexpr (BOXES) {                              //      by its tail, one (mode 2) or two (mode 4) launches from here
+            if (b < Y.nbox) lpf_box_frame_block(X, b, s_raw);
+        }
+        return;
+    }
+    b -= Y.nbox8;
     const int plen = Y.kper + 8, periodic = Y.nper * plen;
     int vblk;                                               // K1: virtual block index, (rank on the XCD) << 3 | XCD
     if (b < periodic) {
@@ -1443,167 +1493,248 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const LpfBoxPre
 }
 
 // ------------------------------------------------------------------------------------
-// BOX SET-UP on the device (per frame, per box change; capturable): from the 8 velodyne-frame corners of every box
+// BOX JOB (per frame, per box change): the reference's per-frame box preparation (V3:556-562) and the tables the counting
+// kernels read, in ONE block per frame -- as a kernel of its own (serial mode, graph capture) or as a role of lpf_step_t
+// (software-pipelined modes: the boxes of run i are prepared by blocks of run i's launch, two launches before its tail
+// counts into them).  From the 8 corners of every box -- cam-0 frame (cam0 = 1: filter_visible_bboxes +
+// transform_bboxes_to_velodyne first, exactly lpf_box_prep_kernel's arithmetic) or velodyne frame --
 //   boxp[b]  the oracle's slab parameters { c0, (v_a, |v_a|^2) x 3, exact_ok }  (oracle/lpf_oracle.c: orc_oriented_inside;
-//            V3:187-197) or { lo, hi } for the axis-aligned test (V3:158-162) -- the same operations in the same order as
+//            V3:187-197) or { lo, hi } for the axis-aligned test (V3:158-162): the same operations in the same order as
 //            the reference's NumPy statements, so the counting kernels decide exactly as it does;
 //   boxq[b]  a conservative float AABB of the accepted region;
-//   cand     bit b of every 32x32-pixel cell the region can project into (the region is convex and the camera a
-//            pinhole, so the projections of its 8 vertices bound its image; a region reaching behind the camera, or an
-//            unbounded / degenerate one, is a candidate everywhere).
-// boxq and cand only skip hopeless (point, box) pairs: every candidate still takes the exact test.  One wave per box;
-// a box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no candidate cell.
+//   cand     per 32x32-pixel cell the bit set of the boxes whose accepted region can project into it (the region is convex
+//            and the camera a pinhole, so the projections of its 8 vertices bound its image; a region reaching behind the
+//            camera, or an unbounded / degenerate one, is a candidate everywhere).
+// boxq and cand only skip hopeless (point, box) pairs: every candidate still takes the exact test.
+// Eight lanes share a box (lane = corner, then lane = vertex of the accepted region), 32 boxes per pass of the block; each
+// box leaves its cell rectangle in LDS, and the grid is then GATHERED -- thread = (cell, word), a loop over the word's 64
+// boxes -- so every word is written exactly once, in full: no atomics, no memset in front, nothing to clean afterwards.
+// A box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no candidate cell.
 // ------------------------------------------------------------------------------------
-struct LpfBoxFrame {             // per frame, host-built from the box counts
-    int box_off, B;
-    long long cand_off;          // first word of the frame's grid
-};
-
-struct LpfBoxSetup {
-    double T[12], K[9];
-    int W, H, cell_shift, cell_w, cell_h, oriented, F, Btot;
-};
-
-__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_setup_kernel(const LpfBoxSetup A, const double *__restrict__ corners,
-                                                                  const uint8_t *__restrict__ enabled,
-                                                                  const LpfBoxFrame *__restrict__ bframes,
-                                                                  double *__restrict__ boxp, float *__restrict__ boxq,
-                                                                  unsigned long long *__restrict__ cand)
+__device__ __forceinline__ double lpf_min8(double x)   // over the 8 lanes that share a box (contiguous, 8-aligned)
 {
-    const int lane = lpf_lane();
-    const int gb = blockIdx.x * 4 + lpf_wave();
-    if (gb >= A.Btot) return;                               // wave-uniform
-    int f = 0;                                              // the frame of the box: last f with box_off <= gb
-    {
-        int lo = 0, hi = A.F;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (bframes[mid].box_off <= gb) lo = mid; else hi = mid;
-        }
-        f = lo;
+    x = fmin(x, __shfl_xor(x, 1)); x = fmin(x, __shfl_xor(x, 2)); return fmin(x, __shfl_xor(x, 4));
+}
+__device__ __forceinline__ double lpf_max8(double x)
+{
+    x = fmax(x, __shfl_xor(x, 1)); x = fmax(x, __shfl_xor(x, 2)); return fmax(x, __shfl_xor(x, 4));
+}
+
+__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int f, char *s_raw)
+{
+    // The work of a box is cut into short phases that hand their results on through LDS (lane = corner -> lane = slab ->
+    // lane = edge of the region -> lane = vertex): inside lpf_step_t the role has 72 registers, and the straight-line form
+    // (every lane everything: 111) spilled.
+    LpfBoxJobLds &L = *reinterpret_cast<LpfBoxJobLds *>(s_raw);
+    const int tid = threadIdx.x;
+    LpfBoxFrame bf = J.frame0;
+    if (J.F > 1) {
+        const LpfBoxFrame t = J.bframes[lpf_uni(f)];
+        bf.box_off = lpf_uni(t.box_off); bf.B = lpf_uni(t.B); bf.cand_off = lpf_uni64(t.cand_off);
     }
-    const LpfBoxFrame bf = bframes[f];
-    const int b = gb - bf.box_off, words = (bf.B + 63) >> 6;
-    const double *__restrict__ c = corners + (size_t)gb * 24;
-    double o[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.0;
-    double lo3[3], hi3[3], vx[8], vy[8], vz[8];
-    bool bounded = true;
-    const bool on = !enabled || enabled[gb] != 0;
-    if (A.oriented) {
-        const int other[3] = {1, 3, 4};
-        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
-        double V[3][3], vv[3];
-        bool ok = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double *q = c + 3 * other[a];
-            const double v0 = q[0] - c[0], v1 = q[1] - c[1], v2 = q[2] - c[2];
-            double w = v0 * v0; w = fma(v1, v1, w); w = fma(v2, v2, w);
-            o[3 + 4 * a] = v0; o[4 + 4 * a] = v1; o[5 + 4 * a] = v2; o[6 + 4 * a] = w;
-            V[a][0] = v0; V[a][1] = v1; V[a][2] = v2; vv[a] = w;
-            if (!(w >= 1e-100 && w <= 1e100)) ok = false;   // also false for NaN (see lpf_oriented_inside)
-        }
-        o[15] = ok ? 1.0 : 0.0;
-        // region = { p : 0 <= (p - c0) . v_a <= vv_a }: its vertices solve V x = sigma * vv, sigma in {0,1}^3
-        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
-                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
-        const double scale = sqrt(vv[0]) * sqrt(vv[1]) * sqrt(vv[2]);
-        if (!ok || !(fabs(det) > 1e-6 * scale)) {
-            bounded = false;
-        } else {
-            double inv[3][3];
-            inv[0][0] = (V[1][1] * V[2][2] - V[1][2] * V[2][1]) / det; inv[0][1] = (V[0][2] * V[2][1] - V[0][1] * V[2][2]) / det;
-            inv[0][2] = (V[0][1] * V[1][2] - V[0][2] * V[1][1]) / det; inv[1][0] = (V[1][2] * V[2][0] - V[1][0] * V[2][2]) / det;
-            inv[1][1] = (V[0][0] * V[2][2] - V[0][2] * V[2][0]) / det; inv[1][2] = (V[0][2] * V[1][0] - V[0][0] * V[1][2]) / det;
-            inv[2][0] = (V[1][0] * V[2][1] - V[1][1] * V[2][0]) / det; inv[2][1] = (V[0][1] * V[2][0] - V[0][0] * V[2][1]) / det;
-            inv[2][2] = (V[0][0] * V[1][1] - V[0][1] * V[1][0]) / det;
-#pragma unroll
-            for (int sg = 0; sg < 8; ++sg) {
-                const double r0 = (sg & 1) ? vv[0] : 0.0, r1 = (sg & 2) ? vv[1] : 0.0, r2 = (sg & 4) ? vv[2] : 0.0;
-                vx[sg] = c[0] + inv[0][0] * r0 + inv[0][1] * r1 + inv[0][2] * r2;
-                vy[sg] = c[1] + inv[1][0] * r0 + inv[1][1] * r1 + inv[1][2] * r2;
-                vz[sg] = c[2] + inv[2][0] * r0 + inv[2][1] * r1 + inv[2][2] * r2;
+    const int B = bf.B, words = (B + 63) >> 6;
+    for (int s0 = 0; s0 < B; s0 += LPF_BOXJOB_CAP) {
+        const int s1 = min(s0 + LPF_BOXJOB_CAP, B);
+        for (int b0 = s0; b0 < s1; b0 += 32) {
+            // (everything that depends on the thread index is derived again in every pass, behind an empty asm: hoisted out of
+            //  the loops, those loop invariants -- addresses, selectors, constants -- cost more registers than the work itself)
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int grp = t_ >> 3, k = t_ & 7;
+            const unsigned long long gmask = 0xFFull << (t_ & 56);
+            double (*C)[3] = L.c[grp];                      // the box's 8 slots of 3 doubles: corners first, then reused (see below)
+            const int b = b0 + grp;
+            const bool live = b < s1;
+            const size_t gb = (size_t)bf.box_off + (size_t)(live ? b : s0);
+            // ---- phase 1, lane = corner: to the velodyne frame (and, cam-0 input, the visibility of the box) -----------------
+            bool on = true;
+            {
+                double x = 0.0, y = 0.0, z = 0.0;
+                if (live) { const double *cc = J.src + (gb * 8 + k) * 3; x = cc[0]; y = cc[1]; z = cc[2]; }
+                if (J.cam0) {
+                    // cam2image on the raw cam-0 corners, WITHOUT R_rect (reference quirk, V3:129-138)
+                    double qx = J.K[0] * x; qx = fma(J.K[1], y, qx); qx = fma(J.K[2], z, qx);
+                    double qy = J.K[3] * x; qy = fma(J.K[4], y, qy); qy = fma(J.K[5], z, qy);
+                    double d  = J.K[6] * x; d  = fma(J.K[7], y, d);  d  = fma(J.K[8], z, d);
+                    if (d == 0.0) d = -1e-6;
+                    const double ad = fabs(d);
+                    const double ru = rint(qx / ad), rv = rint(qy / ad);
+                    const bool in_img = (ru >= 0.0) && (ru < (double)J.W) && (rv >= 0.0) && (rv < (double)J.H);
+                    const bool vis = live && (d > 0.1) && in_img;
+                    const bool frn = live && (d > 0.0);
+                    const int nvis = __popcll(__ballot(vis) & gmask), nfront = __popcll(__ballot(frn) & gmask);
+                    on = !J.filter_visible || nvis >= 2;
+                    if (J.bbox2d) {                         // V4:157-168: min / max of the integer (u, v) over the corners in front
+                        const double umin = lpf_min8(frn ? ru : 1e300), umax = lpf_max8(frn ? ru : -1e300);
+                        const double vmin = lpf_min8(frn ? rv : 1e300), vmax = lpf_max8(frn ? rv : -1e300);
+                        if (live && k == 0) { J.bbox2d[4 * gb] = umin; J.bbox2d[4 * gb + 1] = vmin; J.bbox2d[4 * gb + 2] = umax; J.bbox2d[4 * gb + 3] = vmax; }
+                    }
+                    if (live && k == 0) {
+                        if (J.visible) J.visible[gb] = (uint8_t)(nvis >= 2);
+                        if (J.front) J.front[gb] = nfront;
+                        if (J.enabled_out) J.enabled_out[gb] = (uint8_t)(nvis >= 2);
+                    }
+                    // transform_bboxes_to_velodyne (V3:41-52): rows of inv(TrVeloToCam) as k-ordered fma chains
+                    double a0 = J.Tcv[0] * x; a0 = fma(J.Tcv[1], y, a0); a0 = fma(J.Tcv[2],  z, a0); a0 = fma(J.Tcv[3],  1.0, a0);
+                    double a1 = J.Tcv[4] * x; a1 = fma(J.Tcv[5], y, a1); a1 = fma(J.Tcv[6],  z, a1); a1 = fma(J.Tcv[7],  1.0, a1);
+                    double a2 = J.Tcv[8] * x; a2 = fma(J.Tcv[9], y, a2); a2 = fma(J.Tcv[10], z, a2); a2 = fma(J.Tcv[11], 1.0, a2);
+                    x = a0; y = a1; z = a2;
+                } else if (J.enabled_in) {
+                    on = !live || J.enabled_in[gb] != 0;
+                }
+                if (live) {
+                    if (J.corners_keep) { double *o = J.corners_keep + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
+                    if (J.corners_out) { double *o = J.corners_out + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
+                }
+                C[k][0] = x; C[k][1] = y; C[k][2] = z;
             }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double a = c[k], bb = c[k];
-            for (int j = 1; j < 8; ++j) {
-                const double w = c[3 * j + k];
-                if (w < a) a = w;
-                if (w > bb) bb = w;
+            __builtin_amdgcn_wave_barrier();                // the 8 lanes of a box are lanes of one wave: its LDS queue is in order
+            bool bounded = true;
+            if (J.oriented) {
+                // ---- phase 2, lanes 1..3 = slab a: v_a = c_{1,3,4} - c0, |v_a|^2 -- the exact parameters (V3:187-197) -----------
+                bool ok = true;
+                if (k >= 1 && k <= 3) {
+                    const int a = k - 1, oc = (a == 0) ? 1 : (a == 1) ? 3 : 4;
+                    const double v0 = C[oc][0] - C[0][0], v1 = C[oc][1] - C[0][1], v2 = C[oc][2] - C[0][2];
+                    double w = v0 * v0; w = fma(v1, v1, w); w = fma(v2, v2, w);
+                    ok = (w >= 1e-100 && w <= 1e100);       // also false for NaN (see lpf_oriented_inside)
+                    if (live) {
+                        double *o = J.boxp + gb * 16 + 3 + 4 * a;
+                        o[0] = on ? v0 : 0.0; o[1] = on ? v1 : 0.0; o[2] = on ? v2 : 0.0; o[3] = on ? w : 0.0;
+                    }
+                    C[5 + a][0] = v0; C[5 + a][1] = v1; C[5 + a][2] = v2;       // corners 5..7 are not needed any more
+                    asm volatile("" ::: "memory");
+                    C[4][a] = w;                            // (slab 2 has read corner 4: in-order LDS queue of the wave)
+                }
+                ok = __popcll(__ballot(!ok) & gmask) == 0;
+                if (live && k == 0) {
+                    double *o = J.boxp + gb * 16;
+                    o[0] = on ? C[0][0] : 0.0; o[1] = on ? C[0][1] : 0.0; o[2] = on ? C[0][2] : 0.0; o[15] = (on && ok) ? 1.0 : 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- phase 3, lanes 0..2 = edge a of the region { p : 0 <= (p - c0) . v_a <= |v_a|^2 }: with w_a the reciprocal
+                //      basis (w_a . v_b = delta_ab), e_a = |v_a|^2 w_a, w_a = (v_b x v_c) / det, (a, b, c) cyclic -------------------
+                bool good = true;
+                if (k < 3) {
+                    const int a = k, bb = (a + 1) % 3, cc = (a + 2) % 3;
+                    const double bx = C[5 + bb][0], by = C[5 + bb][1], bz = C[5 + bb][2];
+                    const double cx = C[5 + cc][0], cy = C[5 + cc][1], cz = C[5 + cc][2];
+                    const double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+                    const double det = C[5 + a][0] * nx + C[5 + a][1] * ny + C[5 + a][2] * nz;
+                    const double scale = sqrt(C[4][0]) * sqrt(C[4][1]) * sqrt(C[4][2]);
+                    const double r = C[4][a] / det;
+                    const double ex = nx * r, ey = ny * r, ez = nz * r;
+                    good = (fabs(det) > 1e-6 * scale) && (ex == ex) && (ey == ey) && (ez == ez);
+                    C[1 + a][0] = ex; C[1 + a][1] = ey; C[1 + a][2] = ez;       // corners 1..3 have been read
+                }
+                if (!ok || __popcll(__ballot(!good) & gmask) != 0) bounded = false;
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // point_in_bbox (V3:158-162) as the oracle restates it: lo = c0; if (w < lo) lo = w over corners 1..7 -- a NaN in
+                // corner 0 stays (every comparison with it is false), a NaN elsewhere is skipped: fmin / fmax skip NaNs everywhere.
+                // Lane k < 3 takes coordinate k: the region is the box c0' = lo, edges (hi - lo) along the axes.
+                const double c0k = C[0][k % 3];
+                const double mine = C[k][0], miney = C[k][1], minez = C[k][2];
+                const double l0 = lpf_min8(mine), h0 = lpf_max8(mine), l1 = lpf_min8(miney), h1 = lpf_max8(miney), l2 = lpf_min8(minez), h2 = lpf_max8(minez);
+                double lo = (k % 3 == 0) ? l0 : (k % 3 == 1) ? l1 : l2, hi = (k % 3 == 0) ? h0 : (k % 3 == 1) ? h1 : h2;
+                if (!(c0k == c0k)) { lo = c0k; hi = c0k; }
+                if (live && k < 3) { J.boxp[gb * 16 + k] = on ? lo : 0.0; J.boxp[gb * 16 + 3 + k] = on ? hi : 0.0; }
+                if (live) { J.boxp[gb * 16 + 6 + k] = 0.0; if (k < 2) J.boxp[gb * 16 + 14 + k] = 0.0; }
+                __builtin_amdgcn_wave_barrier();            // every lane has read its corner
+                if (k < 3) {
+                    C[0][k] = lo;                           // origin of the region
+                    C[1 + k][0] = (k == 0) ? hi - lo : 0.0; C[1 + k][1] = (k == 1) ? hi - lo : 0.0; C[1 + k][2] = (k == 2) ? hi - lo : 0.0;
+                }
+                if (__popcll(__ballot(k < 3 && (!isfinite(lo) || !isfinite(hi))) & gmask) != 0) bounded = false;
+                __builtin_amdgcn_wave_barrier();
             }
-            o[k] = a; o[3 + k] = bb;
-            if (!(a == a) || !(bb == bb)) bounded = false;
-        }
-#pragma unroll
-        for (int sg = 0; sg < 8; ++sg) {
-            vx[sg] = (sg & 1) ? o[3] : o[0]; vy[sg] = (sg & 2) ? o[4] : o[1]; vz[sg] = (sg & 4) ? o[5] : o[2];
-        }
-    }
-    if (bounded) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { lo3[k] = 1e300; hi3[k] = -1e300; }
-#pragma unroll
-        for (int sg = 0; sg < 8; ++sg) {
-            lo3[0] = fmin(lo3[0], vx[sg]); hi3[0] = fmax(hi3[0], vx[sg]);
-            lo3[1] = fmin(lo3[1], vy[sg]); hi3[1] = fmax(hi3[1], vy[sg]);
-            lo3[2] = fmin(lo3[2], vz[sg]); hi3[2] = fmax(hi3[2], vz[sg]);
-            if (!(vx[sg] == vx[sg]) || !(vy[sg] == vy[sg]) || !(vz[sg] == vz[sg])) bounded = false;   // fmin/fmax drop NaNs
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) if (!isfinite(lo3[k]) || !isfinite(hi3[k])) bounded = false;
-    }
-    if (lane < 16) boxp[(size_t)gb * 16 + lane] = on ? o[lane] : 0.0;
-    if (lane < 8) {
-        float q = 0.f;
-        const int k = lane & 3;
-        if (k < 3) {
-            if (!on) q = (lane < 4) ? INFINITY : -INFINITY;                       // empty: nothing is near
-            else if (!bounded) q = (lane < 4) ? -INFINITY : INFINITY;
-            else {
-                const double m = 1e-5 * (fabs(lo3[k]) + fabs(hi3[k]) + (hi3[k] - lo3[k])) + 1e-6;
-                q = (lane < 4) ? nextafterf((float)(lo3[k] - m), -INFINITY) : nextafterf((float)(hi3[k] + m), INFINITY);
+            // ---- phase 4, lanes 0..2 = coordinate: conservative float bounds of the region c0 + s0 e0 + s1 e1 + s2 e2, s in [0,1]^3 ----
+            {
+                bool fin = true;
+                if (k < 3) {
+                    const double c0k = C[0][k], e0 = C[1][k], e1 = C[2][k], e2 = C[3][k];
+                    const double lov = c0k + fmin(e0, 0.0) + fmin(e1, 0.0) + fmin(e2, 0.0), hiv = c0k + fmax(e0, 0.0) + fmax(e1, 0.0) + fmax(e2, 0.0);
+                    fin = isfinite(lov) && isfinite(hiv);
+                    C[4][k] = lov; C[5][k] = hiv;
+                }
+                if (__popcll(__ballot(!fin) & gmask) != 0) bounded = false;
+                __builtin_amdgcn_wave_barrier();
+                if (live && k < 6) {                        // {lo xyz, -, hi xyz, -}: lanes 0..2 lo, 3..5 hi
+                    const int kk = k % 3;
+                    const double lov = C[4][kk], hiv = C[5][kk];
+                    float q;
+                    if (!on) q = (k < 3) ? INFINITY : -INFINITY;                      // empty: nothing is near
+                    else if (!bounded) q = (k < 3) ? -INFINITY : INFINITY;
+                    else {
+                        const double m = 1e-5 * (fabs(lov) + fabs(hiv) + (hiv - lov)) + 1e-6;
+                        q = (k < 3) ? nextafterf((float)(lov - m), -INFINITY) : nextafterf((float)(hiv + m), INFINITY);
+                    }
+                    J.boxq[gb * 8 + (k < 3 ? k : k + 1)] = q;
+                }
+                if (live && k >= 6) J.boxq[gb * 8 + (k == 6 ? 3 : 7)] = 0.f;
             }
+            // ---- phase 5, lane = vertex of the region: the image of the 8 vertices bounds the image of the region ---------------
+            bool everywhere = !bounded;
+            double u, w;
+            {
+                const double s0f = (k & 1) ? 1.0 : 0.0, s1f = (k & 2) ? 1.0 : 0.0, s2f = (k & 4) ? 1.0 : 0.0;
+                const double px = C[0][0] + s0f * C[1][0] + s1f * C[2][0] + s2f * C[3][0];
+                const double py = C[0][1] + s0f * C[1][1] + s1f * C[2][1] + s2f * C[3][1];
+                const double pz = C[0][2] + s0f * C[1][2] + s1f * C[2][2] + s2f * C[3][2];
+                const double cx = J.T[0] * px + J.T[1] * py + J.T[2] * pz + J.T[3];
+                const double cy = J.T[4] * px + J.T[5] * py + J.T[6] * pz + J.T[7];
+                const double cz = J.T[8] * px + J.T[9] * py + J.T[10] * pz + J.T[11];
+                const double qx = J.K[0] * cx + J.K[1] * cy + J.K[2] * cz;
+                const double qy = J.K[3] * cx + J.K[4] * cy + J.K[5] * cz;
+                const double d = J.K[6] * cx + J.K[7] * cy + J.K[8] * cz;
+                const bool bad = !(d > 1e-3) || !isfinite(qx) || !isfinite(qy);
+                if (__popcll(__ballot(bad) & gmask) != 0) everywhere = true;
+                u = qx / d; w = qy / d;
+            }
+            double umin = lpf_min8(u), umax = lpf_max8(u), vmin = lpf_min8(w), vmax = lpf_max8(w);
+            int x0 = 0, x1 = J.cell_w - 1, y0 = 0, y1 = J.cell_h - 1;
+            if (!everywhere) {
+                umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;                // rounding of (u, v) + slack
+                if (umax < 0 || vmax < 0 || umin > J.W || vmin > J.H) { x0 = 1; x1 = 0; }       // never seen by a valid point
+                else {
+                    x0 = umin <= 0 ? 0 : (int)umin >> J.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> J.cell_shift;
+                    x1 = umax >= J.W ? J.cell_w - 1 : (int)umax >> J.cell_shift; y1 = vmax >= J.H ? J.cell_h - 1 : (int)vmax >> J.cell_shift;
+                    x1 = min(x1, J.cell_w - 1); y1 = min(y1, J.cell_h - 1);
+                }
+            }
+            if (!on) { x0 = 1; x1 = 0; }
+            if (live && k == 0) {
+                short *r = L.rect[b - s0];
+                r[0] = (short)x0; r[1] = (short)x1; r[2] = (short)y0; r[3] = (short)y1;
+            }
+            __builtin_amdgcn_wave_barrier();                // the slots are rewritten by the next pass
         }
-        boxq[(size_t)gb * 8 + lane] = q;
-    }
-    if (!on) return;
-    // ---- candidate cells --------------------------------------------------------------------------------
-    int x0 = 0, x1 = A.cell_w - 1, y0 = 0, y1 = A.cell_h - 1;
-    bool everywhere = !bounded;
-    if (!everywhere) {
-        double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double cx = A.T[0] * vx[k] + A.T[1] * vy[k] + A.T[2] * vz[k] + A.T[3];
-            const double cy = A.T[4] * vx[k] + A.T[5] * vy[k] + A.T[6] * vz[k] + A.T[7];
-            const double cz = A.T[8] * vx[k] + A.T[9] * vy[k] + A.T[10] * vz[k] + A.T[11];
-            const double qx = A.K[0] * cx + A.K[1] * cy + A.K[2] * cz;
-            const double qy = A.K[3] * cx + A.K[4] * cy + A.K[5] * cz;
-            const double d = A.K[6] * cx + A.K[7] * cy + A.K[8] * cz;
-            if (!(d > 1e-3) || !isfinite(qx) || !isfinite(qy)) { everywhere = true; }
-            const double u = qx / d, v = qy / d;
-            umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+        __syncthreads();
+        // ---- gather: word w of cell (cx, cy) = the boxes 64 w .. 64 w + 63 whose rectangle holds the cell ------------------
+        const int ncell = J.cell_w * J.cell_h, w0 = s0 >> 6, w1 = (s1 + 63) >> 6, nw = w1 - w0;
+        unsigned long long *__restrict__ gf = J.cand + bf.cand_off;
+        int t2_ = tid;
+        asm volatile("" : "+v"(t2_));
+        for (int i = t2_; i < ncell * nw; i += LPF_BLOCK) {
+            const int cell = i / nw, wd = w0 + (i - cell * nw);
+            const int cy = cell / J.cell_w, cx = cell - cy * J.cell_w;
+            unsigned long long bits = 0ull;
+            const int be = min(64, B - (wd << 6));
+            for (int j = 0; j < be; ++j) {
+                const short *r = L.rect[(wd << 6) + j - s0];                      // every lane reads the same entry: a broadcast
+                const int rx0 = r[0], rx1 = r[1], ry0 = r[2], ry1 = r[3];
+                if (cx >= rx0 && cx <= rx1 && cy >= ry0 && cy <= ry1) bits |= 1ull << j;
+            }
+            gf[(size_t)cell * words + wd] = bits;
         }
-        if (!everywhere) {
-            umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;            // rounding of (u, v) + slack
-            if (umax < 0 || vmax < 0 || umin > A.W || vmin > A.H) return;   // never seen by a valid point
-            x0 = umin <= 0 ? 0 : (int)umin >> A.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> A.cell_shift;
-            x1 = umax >= A.W ? A.cell_w - 1 : (int)umax >> A.cell_shift; y1 = vmax >= A.H ? A.cell_h - 1 : (int)vmax >> A.cell_shift;
-            x1 = min(x1, A.cell_w - 1); y1 = min(y1, A.cell_h - 1);
-        }
+        __syncthreads();                                    // the rectangles are rewritten by the next pass
     }
-    unsigned long long *gf = cand + bf.cand_off;
-    const int nx = x1 - x0 + 1, ncell = nx * (y1 - y0 + 1);
-    const unsigned long long bit = 1ull << (b & 63);
-    for (int i = lane; i < ncell; i += 64) {
-        const int y = y0 + i / nx, x = x0 + i % nx;
-        atomicOr(&gf[((size_t)y * A.cell_w + x) * words + (b >> 6)], bit);
-    }
+}
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_box_job_kernel(const LpfBoxJob J)
+{
+    __shared__ __attribute__((aligned(16))) char s_raw[sizeof(LpfBoxJobLds)];
+    lpf_box_frame_block(J, (int)blockIdx.x, s_raw);
 }
 
 // ------------------------------------------------------------------------------------

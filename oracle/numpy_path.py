@@ -62,3 +62,25 @@ def frame_path(points, T, K3, W, H, dmax, masks, corners_velo, min_points=10):
             if n > best_cnt[m]:
                 best_cnt[m], best_box[m] = n, b
     return u, v, valid_indices, lists, count, best_box, best_cnt
+
+
+def prepare_boxes(corners_cam0, K3, W, H, TrVeloToCam):
+    """The reference's per-frame box preparation, restated: filter_visible_bboxes (V3:121-140 -- the cam-0 corners projected
+    with cam2image WITHOUT R_rect, kept when at least 2 corners have depth > 0.1 inside the image) and
+    transform_bboxes_to_velodyne (V3:41-52 -- inv(TrVeloToCam) . [c 1]).  corners_cam0: f64 [B,8,3].
+    Returns (visible bool[B], corners_velo f64[B,8,3] of ALL boxes).  Pinned against the reference-generated golden vectors
+    (visible_pos, corners_velo) in tests/test_oracle_golden.py."""
+    corners_cam0 = np.asarray(corners_cam0, dtype=np.float64).reshape(-1, 8, 3)
+    B = corners_cam0.shape[0]
+    visible = np.zeros(B, bool)
+    velo = np.zeros((B, 8, 3))
+    TrCamToVelo = np.linalg.inv(TrVeloToCam)
+    for b in range(B):
+        corners = corners_cam0[b]
+        u, v, depth = cam2image(K3, corners.T.copy())
+        in_front = depth > 0.1
+        in_image = (u >= 0) & (u < W) & (v >= 0) & (v < H)
+        visible[b] = np.sum(in_front & in_image) >= 2
+        corners_h = np.hstack([corners, np.ones((8, 1))])
+        velo[b] = (TrCamToVelo @ corners_h.T).T[:, :3]
+    return visible, velo

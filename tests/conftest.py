@@ -44,6 +44,30 @@ def calib():
     return load_calib()
 
 
+def lab_library():
+    """liblpf_lab.so: the product's sources compiled with -DLPF_LAB, which adds lpf_set_geometry (the product picks the launch
+    geometry by launch size only).  Built by __graft_entry__.build(); the forced-geometry tests skip without it."""
+    from lidar_object_detection_amd import _build
+    return _build.LAB_LIB if os.path.exists(_build.LAB_LIB) else None
+
+
+FORMS = ["auto", "small", "small-narrow", "large", "large-scan"]
+
+
+def context_for_form(form, device=0):
+    """An LpfContext of the product library ("auto": geometry by launch size, what ships) or of the lab build with the launch
+    geometry forced, so that small inputs reach the code paths of large launches."""
+    from lidar_object_detection_amd._native import LpfContext
+    if form == "auto":
+        return LpfContext(device)
+    lab = lab_library()
+    if lab is None:
+        pytest.skip("liblpf_lab.so has not been built (python -m lidar_object_detection_amd._build lab)")
+    c = LpfContext(device, library=lab)
+    c.set_geometry(form)
+    return c
+
+
 def load_golden_full(frame):
     """Full-size variant (tests/golden/make_golden.py, HASH_FRAMES): inputs in full, long outputs as SHA-256 digests."""
     return dict(np.load(os.path.join(GOLDEN, "frame_%010d_full.npz" % frame)))

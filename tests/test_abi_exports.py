@@ -9,9 +9,11 @@ from lidar_object_detection_amd import _build, _native
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(lab=False):
     text = open(os.path.join(REPO, "include", "lpf.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    if not lab:                         # what only a -DLPF_LAB build declares (and exports)
+        text = re.sub(r"#ifdef LPF_LAB.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lpf_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -24,7 +26,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_native.EXPORTED) == names
     lib.lpf_abi_version.restype = ctypes.c_int
-    assert lib.lpf_abi_version() == 4
+    assert lib.lpf_abi_version() == 5
+    # the measured-slower machinery of ABI 4 is gone from the product, and the geometry override lives in the lab build only
+    assert not hasattr(lib, "lpf_set_cu_partition") and not hasattr(lib, "lpf_set_geometry")
+    assert _declared(lab=True) == sorted(names + ["lpf_set_geometry"])
 
 
 def test_struct_mirrors():

@@ -1,7 +1,8 @@
 """Seeded differential fuzz of the whole HIP path against the CPU oracle: random frame counts and sizes, mask
 counts and densities (including full masks -> dense segments), box counts on both sides of the 64-box candidate
 word, oriented / axis-aligned tests, depth windows, and clouds concentrated inside the camera frustum (dense valid
-runs, as real scans have) -- under every launch geometry (lpf_set_geometry)."""
+runs, as real scans have) -- on the product library (geometry by launch size) and, on the lab build, under every forced
+launch geometry (lpf_set_geometry: the code paths of large launches at small sizes)."""
 import os
 
 import numpy as np
@@ -55,13 +56,12 @@ def _case(seed, calib):
     return T, K, W, H, dmax, oriented, M, frames, masks, boxes
 
 
-@pytest.mark.parametrize("form", ["small", "small-narrow", "large", "large-scan"])
+@pytest.mark.parametrize("form", ["auto", "small-narrow", "large", "large-scan"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24"))))
 def test_fuzz_against_oracle(seed, form, calib):
-    from lidar_object_detection_amd._native import LpfContext
+    from conftest import context_for_form
     T, K, W, H, dmax, oriented, M, frames, masks, boxes = _case(int(os.environ.get("LPF_FUZZ_SEED_BASE", "1000")) + seed, calib)
-    with LpfContext(0) as ctx:
-        ctx.set_geometry(form)
+    with context_for_form(form) as ctx:
         ctx.set_camera(T, K, W, H, 0.0, dmax)
         ctx.set_masks(np.stack(masks))
         ctx.set_boxes(boxes, oriented=oriented)

@@ -18,13 +18,12 @@ I32 = np.iinfo(np.int32)
 TOL = 1e-5
 
 
-@pytest.fixture(scope="module", params=["small", "small-narrow", "large", "large-scan"])
-def ctx(request):
-    """Every parity test runs under each launch geometry (lpf_set_geometry): 1024-point segments, 4096-point segments, and
-    4096-point segments with the prefixes from the scan kernel (the path of frames beyond 16.7 M points)."""
+@pytest.fixture(scope="module")
+def ctx():
+    """One context of the product library for the module: the launch geometry follows the launch size, as it does for users
+    (forced geometries: tests/test_gpu_fuzz.py on the lab build; large launches at full size: tests/test_gpu_headline.py)."""
     from lidar_object_detection_amd._native import LpfContext
     c = LpfContext(0)
-    c.set_geometry(request.param)
     yield c
     c.close()
 
@@ -377,31 +376,22 @@ def test_full_size_properties_2m(ctx, calib):
     _compare(r, o, 8, want_float=False)
 
 
-@pytest.mark.parametrize("pipelined", [False, True, "fused", "fused+lent", "fused+lent+large", "fused-pack", "fused-pack+lent", "fused-pack+lent+large",
-                                       "pack_side", "cus32", "cus64_exclusive_pack_side"])
+@pytest.mark.parametrize("pipelined", [False, "fused", "fused+lent", "fused+lent+large", "fused-pack", "fused-pack+lent", "fused-pack+lent+large"])
 def test_device_mode_back_to_back_runs(calib, pipelined):
-    """Device-pointer mode (torch tensors): several different batches enqueued back to back without
-    host syncs, with and without the tail kernels on a second stream (optionally with the mask pack on a third, and
-    with the side streams confined to a CU partition); every run must equal the oracle."""
+    """Device-pointer mode (torch tensors): several different batches enqueued back to back without host syncs, in order and
+    in the software-pipelined modes (masks packed at the call, or lent; "+large": the large launch geometry forced on the lab
+    build, where mode 4 lets the pack ride and mode 2 packs by a launch of its own); every run must equal the oracle."""
     import torch
+    from conftest import context_for_form
     from lidar_object_detection_amd import synthetic as S
-    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    from lidar_object_detection_amd._native import SUMMARY_DTYPE
     _, T, K, W, H = S.default_calibration(calib)
     dev = torch.device("cuda", 0)
-    ctx = LpfContext(0)
-    if pipelined == "cus64_exclusive_pack_side":
-        ctx.set_cu_partition(64, exclusive=True)            # needs the context's own stream
-    else:
-        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        if pipelined == "cus32":
-            ctx.set_cu_partition(32)
-    # software-pipelined modes: masks packed at the call / lent (a small launch's tiles then read them directly; with the large
-    # geometry forced, mode 4 lets their pack ride in the run's launch and mode 2 packs them by a launch of its own)
     fmode = pipelined.split("+")[0] if isinstance(pipelined, str) and pipelined.startswith("fused") else None
     lent = isinstance(pipelined, str) and "+lent" in pipelined
-    if fmode and pipelined.endswith("+large"):
-        ctx.set_geometry("large")
-    ctx.set_pipelined(fmode if fmode else bool(pipelined), pack_side=isinstance(pipelined, str) and "pack_side" in pipelined)
+    ctx = context_for_form("large" if (fmode and pipelined.endswith("+large")) else "auto")
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_pipelined(fmode if fmode else False)
     ctx.set_camera(T, K, W, H, 0.0, 30.0)
     F, M, Bx = 3, 5, 7
     runs = []

@@ -64,7 +64,7 @@ def test_device_mode_is_ordered_without_a_device_sync(calib, how):
         if how == "shared_default_stream":
             ctx.set_stream(cur.cuda_stream)                 # handle 0: the null stream itself
         elif how == "own_stream_pipelined_with_edges":
-            ctx.set_pipelined(True, pack_side=True)
+            ctx.set_pipelined("fused-pack")
         ctx.set_camera(T, K, W, H, 0.0, 30.0)
         ctx.set_boxes(sc["corners_velo"])
         # warm run on other data: scratch allocation / table uploads (which synchronise) happen here, not below
@@ -87,6 +87,9 @@ def test_device_mode_is_ordered_without_a_device_sync(calib, how):
 
 
 def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
+    """A graph bakes in pointers to the context's tables.  A batch of several frames has geometry tables (frame records,
+    per-segment records, tail block table): another batch shape rewrites them, and the graph must be refused afterwards.
+    (A run of ONE frame has no table -- its record travels by value -- so single-frame graphs of different sizes coexist.)"""
     import torch
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, LpfError, SUMMARY_DTYPE
@@ -94,14 +97,17 @@ def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
     dev = torch.device("cuda", 0)
     n, M, Bx = 50_000, 4, 5
     sc = S.scene(n, n_masks=M, n_boxes=Bx, seed=91)
+    empty = np.zeros((0, 8, 3))
     with LpfContext(0) as ctx:
         ctx.set_camera(T, K, W, H, 0.0, 30.0)
-        ctx.set_boxes(sc["corners_velo"])
-        pts = torch.from_numpy(sc["points"]).to(dev)
-        masks = torch.from_numpy(sc["masks"]).to(dev).unsqueeze(0)
-        o = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        pts = torch.from_numpy(np.concatenate([sc["points"], sc["points"][:1000]])).to(dev)      # frame 0: the scene, frame 1: a short one
+        masks = torch.from_numpy(np.stack([sc["masks"], sc["masks"]])).to(dev)
+        o = _outputs(torch, dev, n + 1000, M, Bx, SUMMARY_DTYPE.itemsize)
+        o["summary"] = torch.zeros(2 * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        o["inst_idx"] = torch.empty((2, n), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
-        step = ctx.make_device_step(pts, np.array([0, n], np.int64), masks_u8=masks, inst_cap=n, **o)
+        ctx.set_boxes([sc["corners_velo"], empty])
+        step = ctx.make_device_step(pts, np.array([0, n, n + 1000], np.int64), masks_u8=masks, inst_cap=n, **o)
         step()
         ctx.sync()
         ctx.graph_begin()
@@ -109,26 +115,45 @@ def test_stale_graph_is_refused_and_failed_capture_is_abandoned(calib):
         g = ctx.graph_end()
         ctx.graph_launch(g)                                 # fresh: replays
         ctx.sync()
-        _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
-        # another geometry rewrites the frame table the graph points at -> the graph must be refused afterwards
-        half = make = ctx.make_device_step(pts[:n // 2], np.array([0, n // 2], np.int64), masks_u8=masks, inst_cap=n, **o)
-        half()
+        first = {k: (v[:n] if k in ("uv", "label_bits", "valid_idx") else v) for k, v in o.items()}
+        first["inst_idx"] = o["inst_idx"][0]
+        _check(first, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+        # another batch shape rewrites the tables the graph points at -> the graph must be refused afterwards
+        other = ctx.make_device_step(pts, np.array([0, n // 2, n + 1000], np.int64), masks_u8=masks, inst_cap=n, **o)
+        other()
         ctx.sync()
         with pytest.raises(LpfError) as ei:
             ctx.graph_launch(g)
         assert ei.value.code == -3 and "stale" in str(ei.value)
         ctx.graph_destroy(g)
-        # an error inside a capture (here: a geometry that needs a table upload, which cannot be captured) abandons the
+        # an error inside a capture (here: a batch shape that needs a table upload, which cannot be captured) abandons the
         # capture instead of leaving the stream in capture mode
         ctx.graph_begin()
         with pytest.raises(LpfError):
-            step()                                          # full size again: frame table differs -> needs a sync
+            step()                                          # the first shape again: its tables have to travel -> not capturable
         with pytest.raises(LpfError):
             ctx.graph_end()                                 # nothing is being captured any more
         step()                                              # and the context is usable
         ctx.sync()
-        _check(o, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
-        del make
+        _check(first, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+        # single frames carry no table: graphs of two different sizes stay valid side by side
+        ctx.set_boxes(sc["corners_velo"])
+        o1 = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        o2 = _outputs(torch, dev, n, M, Bx, SUMMARY_DTYPE.itemsize)
+        full = ctx.make_device_step(pts[:n], np.array([0, n], np.int64), masks_u8=masks[:1], inst_cap=n, **o1)
+        part = ctx.make_device_step(pts[:n // 2], np.array([0, n // 2], np.int64), masks_u8=masks[:1], inst_cap=n, **o2)
+        full(); part()
+        ctx.sync()
+        ctx.graph_begin(); full(); g_full = ctx.graph_end()
+        ctx.graph_begin(); part(); g_part = ctx.graph_end()
+        for t in o1.values():
+            t.zero_()
+        torch.cuda.synchronize(dev)
+        ctx.graph_launch(g_part)
+        ctx.graph_launch(g_full)
+        ctx.sync()
+        _check(o1, sc, T, K, W, H, M, Bx, SUMMARY_DTYPE)
+        ctx.graph_destroy(g_full); ctx.graph_destroy(g_part)
 
 
 @pytest.mark.parametrize("mode", ["fused", "fused+lent", "fused-pack", "fused-pack+lent"])
@@ -141,12 +166,14 @@ def test_software_pipelined_mode_across_state_changes(calib, mode):
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     _, T, K, W, H = S.default_calibration(calib)
     dev = torch.device("cuda", 0)
+    from conftest import lab_library
+    lab = lab_library()                                     # forced geometries only exist in the lab build; without it: by launch size
     plan = [  # (sizes per frame, masks, boxes, depth max, geometry)
         ([40_000, 9_000], 4, 6, 30.0, "auto"), ([40_000, 9_000], 4, 6, 30.0, "auto"), ([40_000, 9_000], 4, 6, 50.0, "auto"),
         ([25_000], 7, 3, 50.0, "auto"), ([25_000], 7, 11, 50.0, "large"), ([70_001, 5, 300], 2, 11, 20.0, "small"),
         ([70_001, 5, 300], 2, 11, 20.0, "large-scan"), ([12_345], 0, 0, 20.0, "auto"), ([12_345], 3, 5, 20.0, "auto")]
     runs = []
-    with LpfContext(0) as ctx:
+    with LpfContext(0, library=lab) as ctx:
         ctx.set_pipelined(mode.split("+")[0])
         for k, (sizes, M, Bx, dmax, geo) in enumerate(plan):
             scenes = [S.scene(max(n, 1), n_masks=max(M, 1), n_boxes=max(Bx, 1), seed=300 + 10 * k + f) for f, n in enumerate(sizes)]
@@ -159,7 +186,8 @@ def test_software_pipelined_mode_across_state_changes(calib, mode):
                      summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
             masks = torch.from_numpy(np.stack([sc["masks"][:M] for sc in scenes])).to(dev) if M else None
             torch.cuda.synchronize(dev)                     # inputs are ready (the context runs on its own stream)
-            ctx.set_geometry(geo)
+            if lab:
+                ctx.set_geometry(geo)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
                 ctx.set_masks(masks, lend="+lent" in mode)   # lent: read directly by a small launch's tiles, or packed by blocks of a large one

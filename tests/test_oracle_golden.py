@@ -130,3 +130,17 @@ def test_depth_maps_match_reference_loop(calib):
         assert np.array_equal(dm.ravel()[flat], g["depthmap_val_rect5"][off[i]:off[i + 1]])
     vi = g["valid_idx_d30"]
     assert set(np.unique(win[win >= 0])) <= set(vi.tolist()) and (win >= 0).sum() == np.count_nonzero(D)
+
+
+@pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])
+def test_box_preparation_restatement_matches_reference(rec, calib):
+    """oracle/numpy_path.prepare_boxes (filter_visible_bboxes + transform_bboxes_to_velodyne, V3:121-140 / V3:41-52) against
+    what the reference's own functions produced for every sample frame: which boxes are kept, and their velodyne corners."""
+    from oracle import numpy_path as npp
+    g = load_golden(rec["frame"])
+    if "corners_cam0_raw" not in g:
+        pytest.skip("no boxes for this frame")
+    vis, velo = npp.prepare_boxes(g["corners_cam0_raw"], np.asarray(calib["K"])[:, :3], int(calib["width"]), int(calib["height"]),
+                                  calib["TrVeloToCam"])
+    assert np.array_equal(np.flatnonzero(vis), g["visible_pos"])
+    assert np.array_equal(velo[g["visible_pos"]], g["corners_velo"])
