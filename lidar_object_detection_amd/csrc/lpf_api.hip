@@ -81,6 +81,7 @@ struct lpf_ctx {
         std::vector<LpfBoxFrame> h_bframes, h_bframes_dev;   // per-frame records: being built / in HBM (F > 1 only)
         std::vector<long long> cand_off;          // [F] first word of frame f's grid
         size_t cand_words = 0;                    // words of the whole grid
+        int max_words = 1;                        // 64-bit words per cell of the frame with the most boxes
         DevBuf boxp;                              // [Btot][16] double
         DevBuf boxq;                              // [Btot][8] float conservative AABB
         DevBuf cand;                              // candidate-box grid
@@ -209,6 +210,9 @@ void box_job_camera(const lpf_ctx *c, LpfBoxJob &J)
     J.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT; J.cell_h = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
 }
 
+// blocks of a set's box job: frames x 64-box chunks of the frame with the most boxes
+int box_job_blocks(const lpf_ctx::BoxSet &B) { return B.F * B.job.chunks; }
+
 // the box job of a set as a kernel of its own, on the context's stream (serial mode, graph capture, drains)
 int launch_box_job(lpf_ctx *c, lpf_ctx::BoxSet &B)
 {
@@ -217,7 +221,7 @@ int launch_box_job(lpf_ctx *c, lpf_ctx::BoxSet &B)
     if (B.F == 0 || B.box_off[B.F] == 0) return LPF_OK;
     box_job_camera(c, B.job);
     ++c->stats[4];
-    hipLaunchKernelGGL(lpf_box_job_kernel, dim3((unsigned)B.F), dim3(LPF_BLOCK), 0, c->stream, B.job);
+    hipLaunchKernelGGL(lpf_box_job_kernel, dim3((unsigned)box_job_blocks(B)), dim3(LPF_BLOCK), 0, c->stream, B.job);
     LPF_HIP(c, hipGetLastError());
     return LPF_OK;
 }
@@ -242,7 +246,7 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     if (XB) XB->job_valid = false;
     if (boxes) box_job_camera(c, XB->job);
     const LpfBoxJob &XJ = boxes ? XB->job : nojob;
-    Y.nbox = boxes ? XB->F : 0;
+    Y.nbox = boxes ? box_job_blocks(*XB) : 0;
     Y.nbox8 = (Y.nbox + 7) & ~7;
     Y.ntail = Q.valid ? Q.ntail : 0;
     Y.nk1 = KK.valid ? KK.nk1 : 0;
@@ -459,12 +463,14 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
     const size_t ncell = (size_t)cw * ch;
     B->h_bframes.resize((size_t)F);
     B->cand_off.assign((size_t)F, 0);
+    B->max_words = 1;
     size_t total = 0;
     for (int f = 0; f < F; ++f) {
         const int nb = box_off[f + 1] - box_off[f];
         B->h_bframes[f].box_off = box_off[f]; B->h_bframes[f].B = nb; B->h_bframes[f].cand_off = (long long)total;
         B->cand_off[f] = (long long)total;
         total += ncell * (size_t)((nb + 63) / 64);
+        if ((nb + 63) / 64 > B->max_words) B->max_words = (nb + 63) / 64;
     }
     const int Btot = F ? box_off[F] : 0;
     const size_t nb = (size_t)(Btot ? Btot : 1);
@@ -496,7 +502,7 @@ void box_rebuild_job(lpf_ctx::BoxSet &B)
     memset(&J, 0, sizeof J);
     J.src = (const double *)B.corners.p;
     J.enabled_in = B.have_enabled ? (const uint8_t *)B.enabled.p : nullptr;
-    J.oriented = B.oriented; J.F = B.F;
+    J.oriented = B.oriented; J.F = B.F; J.chunks = B.max_words;
     J.bframes = (const LpfBoxFrame *)B.bframes.p;
     if (B.F > 0) J.frame0 = B.h_bframes[0];
     J.boxp = (double *)B.boxp.p; J.boxq = (float *)B.boxq.p; J.cand = (unsigned long long *)B.cand.p;
@@ -534,7 +540,7 @@ int set_boxes_impl(lpf_ctx *c, const double *corners, int on_device, const int32
     if (host_out && (rc = reserve(c, B->aux, nb * 36))) { B->F = 0; return rc; }
     LpfBoxJob &J = B->job;
     memset(&J, 0, sizeof J);
-    J.src = src; J.cam0 = cam0 ? 1 : 0; J.filter_visible = filter_visible ? 1 : 0; J.oriented = B->oriented; J.F = F;
+    J.src = src; J.cam0 = cam0 ? 1 : 0; J.filter_visible = filter_visible ? 1 : 0; J.oriented = B->oriented; J.F = F; J.chunks = B->max_words;
     if (cam0) memcpy(J.Tcv, Tcv, sizeof J.Tcv);
     J.bframes = (const LpfBoxFrame *)B->bframes.p; J.frame0 = B->h_bframes[0];
     J.boxp = (double *)B->boxp.p; J.boxq = (float *)B->boxq.p; J.cand = (unsigned long long *)B->cand.p;
@@ -545,9 +551,9 @@ int set_boxes_impl(lpf_ctx *c, const double *corners, int on_device, const int32
         else if (host_out) { J.bbox2d = (double *)B->aux.p; J.front = (int32_t *)((char *)B->aux.p + nb * 32); }
     }
     B->job_valid = true;
-    if (host_out || !c->fused || c->capturing) {
-        if ((rc = launch_box_job(c, *B))) return rc;
-    }
+    // The job waits for the next lpf_run* and rides in the launch of its streaming tiles (every mode: in order too the tables are
+    // only read by the tail, one launch later) -- unless the caller wants results in host memory now.
+    if (host_out && (rc = launch_box_job(c, *B))) return rc;
     if (host_out) {
         if (visible) LPF_HIP(c, hipMemcpyAsync(visible, B->enabled.p, nb, hipMemcpyDeviceToHost, c->stream));
         if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, B->corners.p, nb * 192, hipMemcpyDeviceToHost, c->stream));
@@ -1195,7 +1201,15 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         c->parity = (c->parity + 1) % (c->defer ? 4 : 3);
         return LPF_OK;
     }
-    if ((rc = launch_box_job(c, BX))) return rc;           // (serial mode: only a rebuild after a camera change is still waiting here)
+    if (BX.job_valid && nk1 > 0 && BX.F > 0 && BX.box_off[BX.F] > 0) {
+        // in order, with a box job waiting: the tiles and the job share one launch (lpf_step_t with those two roles), the tail
+        // that reads the tables follows in the next -- the same number of launches as with boxes that never change
+        lpf_ctx::Pending cur, none;
+        cur.valid = true; cur.P = P; cur.pre = false; cur.ntail = 0; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
+        cur.direct = direct; cur.dsel = c->lazy.f32 ? c->lazy.mode : 0;
+        if ((rc = launch_step(c, cur, none, none, false, lb, &BX, e1))) return rc;
+    } else {
+    if ((rc = launch_box_job(c, BX))) return rc;           // (no tiles to ride with)
     if (nk1 > 0) {
         const dim3 g1((unsigned)nk1);
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
@@ -1210,6 +1224,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 #undef LPF_K1_LAUNCH
         LPF_HIP(c, hipGetLastError());
         if (e1) LPF_HIP(c, hipEventRecord(e1, c->stream));
+    }
     }
     // ---- the tail: lists and box counts in one launch (a wave per segment each, side by side), then the per-frame summaries ----
     if (pre_scan && nseg_total > 0) {
@@ -1386,6 +1401,7 @@ int lpf_graph_end(lpf_ctx *c, lpf_graph **out)
     if (!c || !out) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     if (!c->capturing) return fail(c, LPF_ERR_STATE, "lpf_graph_end without lpf_graph_begin");
+    { int rc_ = launch_box_job(c, c->bx[c->box_cur]); if (rc_) return rc_; }      // boxes set last in the capture, with no run behind them
     c->capturing = false;
     lpf_graph *g = new (std::nothrow) lpf_graph();
     if (!g) return fail(c, LPF_ERR_NOMEM, "out of host memory");

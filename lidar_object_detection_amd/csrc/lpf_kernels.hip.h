@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 // ------------------------------------------------------------------------------------
 struct LpfStepLayout {
     int nfin, nfin8;             // summary blocks (frames of run i-2), padded
-    int nbox, nbox8;             // box-job blocks (frames of the run whose boxes were set since the last launch), padded
+    int nbox, nbox8;             // box-job blocks (frames x 64-box chunks of the run whose boxes were set since the last launch), padded
     int ntail;                   // tail blocks of run i-1
     int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
     int nk1;                     // K1 tiles of run i
@@ -1314,7 +1314,7 @@ struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_
     int cam0, filter_visible, oriented, F;
     double Tcv[12];              // rows 0..2 of inv(TrVeloToCam) (cam0 = 1)
     double T[12], K[9];          // TrVeloToRect rows 0..2, camera.K[:3,:3]
-    int W, H, cell_shift, cell_w, cell_h, nblk;      // nblk: blocks of the role (= F)
+    int W, H, cell_shift, cell_w, cell_h, chunks;    // chunks: blocks per frame = 64-bit words of the frame with the most boxes
     const LpfBoxFrame *bframes;  // [F] (F > 1)
     LpfBoxFrame frame0;          // ... by value for one frame
     double *boxp; float *boxq; unsigned long long *cand;
@@ -1322,14 +1322,11 @@ struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_
     uint8_t *enabled_out;        // [Btot] the context's copy of `visible` (cam0 = 1), or null
     uint8_t *visible; double *corners_out; double *bbox2d; int32_t *front;      // optional outputs of lpf_set_boxes_cam0 (device memory)
 };
-#define LPF_BOXJOB_CAP 1024       // boxes of a frame whose rectangles are staged at a time (more: further passes)
-
 struct LpfBoxJobLds {
-    double c[32][8][3];           // velodyne-frame corners of the pass's 32 boxes
-    short rect[LPF_BOXJOB_CAP][4];   // {x0, x1, y0, y1} in cells; x0 > x1 = no cell
+    double c[32][8][3];           // velodyne-frame corners of the pass's 32 boxes, then its intermediate results (8 slots per box)
 };
 
-__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int f, char *s_raw);
+__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int blk, char *s_raw);
 struct LpfPackJob {              // uint8 masks [F][M][H][W] -> label image [F][H][W] of the step's LT (lpf_pack16_block)
     const uint8_t *masks;
     void *label;
@@ -1506,9 +1503,10 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const LpfBoxPre
 //            and the camera a pinhole, so the projections of its 8 vertices bound its image; a region reaching behind the
 //            camera, or an unbounded / degenerate one, is a candidate everywhere).
 // boxq and cand only skip hopeless (point, box) pairs: every candidate still takes the exact test.
-// Eight lanes share a box (lane = corner, then lane = vertex of the accepted region), 32 boxes per pass of the block; each
-// box leaves its cell rectangle in LDS, and the grid is then GATHERED -- thread = (cell, word), a loop over the word's 64
-// boxes -- so every word is written exactly once, in full: no atomics, no memset in front, nothing to clean afterwards.
+// Eight lanes share a box (lane = corner, then lane = vertex of the accepted region), 32 boxes per pass of the block.  The
+// block first stores zeros over its frame's grid, then every box ORs its bit into the cells of its rectangle (integer atomics
+// in the one L2 the block's CU writes through): no memset launch in front, nothing to clean afterwards, work proportional to
+// the cells the boxes cover.
 // A box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no candidate cell.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double lpf_min8(double x)   // over the 8 lanes that share a box (contiguous, 8-aligned)
@@ -1520,214 +1518,224 @@ __device__ __forceinline__ double lpf_max8(double x)
     x = fmax(x, __shfl_xor(x, 1)); x = fmax(x, __shfl_xor(x, 2)); return fmax(x, __shfl_xor(x, 4));
 }
 
-__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int f, char *s_raw)
+// 1 / x for the work-skipping structures only (float bounds, candidate cells: margins of 1e-5 and 2 pixels): the hardware
+// reciprocal and one Newton step (~2^-50), a fifth of the IEEE division's chain
+__device__ __forceinline__ double lpf_rcp_approx(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+__device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int blk, char *s_raw)
 {
     // The work of a box is cut into short phases that hand their results on through LDS (lane = corner -> lane = slab ->
     // lane = edge of the region -> lane = vertex): inside lpf_step_t the role has 72 registers, and the straight-line form
-    // (every lane everything: 111) spilled.
+    // (every lane everything: 111) spilled.  A block is one dependent chain with nothing beside it to hide latency, so the
+    // chain is kept short: shared-reciprocal division where the reference's quotient is needed (lpf_div2, bit-equal to '/'),
+    // approximate reciprocals where only the conservative structures are concerned, no square root -- and a block takes only 64
+    // boxes of its frame, ONE word of every grid cell: block blk = (frame blk / chunks, word blk % chunks), chunks = the
+    // words of the frame with the most boxes (a frame with fewer leaves its surplus blocks at once).
     LpfBoxJobLds &L = *reinterpret_cast<LpfBoxJobLds *>(s_raw);
     const int tid = threadIdx.x;
+    const int f = blk / J.chunks, wd = blk - f * J.chunks;
     LpfBoxFrame bf = J.frame0;
     if (J.F > 1) {
         const LpfBoxFrame t = J.bframes[lpf_uni(f)];
         bf.box_off = lpf_uni(t.box_off); bf.B = lpf_uni(t.B); bf.cand_off = lpf_uni64(t.cand_off);
     }
-    const int B = bf.B, words = (B + 63) >> 6;
-    for (int s0 = 0; s0 < B; s0 += LPF_BOXJOB_CAP) {
-        const int s1 = min(s0 + LPF_BOXJOB_CAP, B);
-        for (int b0 = s0; b0 < s1; b0 += 32) {
-            // (everything that depends on the thread index is derived again in every pass, behind an empty asm: hoisted out of
-            //  the loops, those loop invariants -- addresses, selectors, constants -- cost more registers than the work itself)
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int grp = t_ >> 3, k = t_ & 7;
-            const unsigned long long gmask = 0xFFull << (t_ & 56);
-            double (*C)[3] = L.c[grp];                      // the box's 8 slots of 3 doubles: corners first, then reused (see below)
-            const int b = b0 + grp;
-            const bool live = b < s1;
-            const size_t gb = (size_t)bf.box_off + (size_t)(live ? b : s0);
-            // ---- phase 1, lane = corner: to the velodyne frame (and, cam-0 input, the visibility of the box) -----------------
-            bool on = true;
-            {
-                double x = 0.0, y = 0.0, z = 0.0;
-                if (live) { const double *cc = J.src + (gb * 8 + k) * 3; x = cc[0]; y = cc[1]; z = cc[2]; }
-                if (J.cam0) {
-                    // cam2image on the raw cam-0 corners, WITHOUT R_rect (reference quirk, V3:129-138)
-                    double qx = J.K[0] * x; qx = fma(J.K[1], y, qx); qx = fma(J.K[2], z, qx);
-                    double qy = J.K[3] * x; qy = fma(J.K[4], y, qy); qy = fma(J.K[5], z, qy);
-                    double d  = J.K[6] * x; d  = fma(J.K[7], y, d);  d  = fma(J.K[8], z, d);
-                    if (d == 0.0) d = -1e-6;
-                    const double ad = fabs(d);
-                    const double ru = rint(qx / ad), rv = rint(qy / ad);
-                    const bool in_img = (ru >= 0.0) && (ru < (double)J.W) && (rv >= 0.0) && (rv < (double)J.H);
-                    const bool vis = live && (d > 0.1) && in_img;
-                    const bool frn = live && (d > 0.0);
-                    const int nvis = __popcll(__ballot(vis) & gmask), nfront = __popcll(__ballot(frn) & gmask);
-                    on = !J.filter_visible || nvis >= 2;
-                    if (J.bbox2d) {                         // V4:157-168: min / max of the integer (u, v) over the corners in front
-                        const double umin = lpf_min8(frn ? ru : 1e300), umax = lpf_max8(frn ? ru : -1e300);
-                        const double vmin = lpf_min8(frn ? rv : 1e300), vmax = lpf_max8(frn ? rv : -1e300);
-                        if (live && k == 0) { J.bbox2d[4 * gb] = umin; J.bbox2d[4 * gb + 1] = vmin; J.bbox2d[4 * gb + 2] = umax; J.bbox2d[4 * gb + 3] = vmax; }
-                    }
-                    if (live && k == 0) {
-                        if (J.visible) J.visible[gb] = (uint8_t)(nvis >= 2);
-                        if (J.front) J.front[gb] = nfront;
-                        if (J.enabled_out) J.enabled_out[gb] = (uint8_t)(nvis >= 2);
-                    }
-                    // transform_bboxes_to_velodyne (V3:41-52): rows of inv(TrVeloToCam) as k-ordered fma chains
-                    double a0 = J.Tcv[0] * x; a0 = fma(J.Tcv[1], y, a0); a0 = fma(J.Tcv[2],  z, a0); a0 = fma(J.Tcv[3],  1.0, a0);
-                    double a1 = J.Tcv[4] * x; a1 = fma(J.Tcv[5], y, a1); a1 = fma(J.Tcv[6],  z, a1); a1 = fma(J.Tcv[7],  1.0, a1);
-                    double a2 = J.Tcv[8] * x; a2 = fma(J.Tcv[9], y, a2); a2 = fma(J.Tcv[10], z, a2); a2 = fma(J.Tcv[11], 1.0, a2);
-                    x = a0; y = a1; z = a2;
-                } else if (J.enabled_in) {
-                    on = !live || J.enabled_in[gb] != 0;
-                }
-                if (live) {
-                    if (J.corners_keep) { double *o = J.corners_keep + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
-                    if (J.corners_out) { double *o = J.corners_out + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
-                }
-                C[k][0] = x; C[k][1] = y; C[k][2] = z;
-            }
-            __builtin_amdgcn_wave_barrier();                // the 8 lanes of a box are lanes of one wave: its LDS queue is in order
-            bool bounded = true;
-            if (J.oriented) {
-                // ---- phase 2, lanes 1..3 = slab a: v_a = c_{1,3,4} - c0, |v_a|^2 -- the exact parameters (V3:187-197) -----------
-                bool ok = true;
-                if (k >= 1 && k <= 3) {
-                    const int a = k - 1, oc = (a == 0) ? 1 : (a == 1) ? 3 : 4;
-                    const double v0 = C[oc][0] - C[0][0], v1 = C[oc][1] - C[0][1], v2 = C[oc][2] - C[0][2];
-                    double w = v0 * v0; w = fma(v1, v1, w); w = fma(v2, v2, w);
-                    ok = (w >= 1e-100 && w <= 1e100);       // also false for NaN (see lpf_oriented_inside)
-                    if (live) {
-                        double *o = J.boxp + gb * 16 + 3 + 4 * a;
-                        o[0] = on ? v0 : 0.0; o[1] = on ? v1 : 0.0; o[2] = on ? v2 : 0.0; o[3] = on ? w : 0.0;
-                    }
-                    C[5 + a][0] = v0; C[5 + a][1] = v1; C[5 + a][2] = v2;       // corners 5..7 are not needed any more
-                    asm volatile("" ::: "memory");
-                    C[4][a] = w;                            // (slab 2 has read corner 4: in-order LDS queue of the wave)
-                }
-                ok = __popcll(__ballot(!ok) & gmask) == 0;
-                if (live && k == 0) {
-                    double *o = J.boxp + gb * 16;
-                    o[0] = on ? C[0][0] : 0.0; o[1] = on ? C[0][1] : 0.0; o[2] = on ? C[0][2] : 0.0; o[15] = (on && ok) ? 1.0 : 0.0;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- phase 3, lanes 0..2 = edge a of the region { p : 0 <= (p - c0) . v_a <= |v_a|^2 }: with w_a the reciprocal
-                //      basis (w_a . v_b = delta_ab), e_a = |v_a|^2 w_a, w_a = (v_b x v_c) / det, (a, b, c) cyclic -------------------
-                bool good = true;
-                if (k < 3) {
-                    const int a = k, bb = (a + 1) % 3, cc = (a + 2) % 3;
-                    const double bx = C[5 + bb][0], by = C[5 + bb][1], bz = C[5 + bb][2];
-                    const double cx = C[5 + cc][0], cy = C[5 + cc][1], cz = C[5 + cc][2];
-                    const double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
-                    const double det = C[5 + a][0] * nx + C[5 + a][1] * ny + C[5 + a][2] * nz;
-                    const double scale = sqrt(C[4][0]) * sqrt(C[4][1]) * sqrt(C[4][2]);
-                    const double r = C[4][a] / det;
-                    const double ex = nx * r, ey = ny * r, ez = nz * r;
-                    good = (fabs(det) > 1e-6 * scale) && (ex == ex) && (ey == ey) && (ez == ez);
-                    C[1 + a][0] = ex; C[1 + a][1] = ey; C[1 + a][2] = ez;       // corners 1..3 have been read
-                }
-                if (!ok || __popcll(__ballot(!good) & gmask) != 0) bounded = false;
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // point_in_bbox (V3:158-162) as the oracle restates it: lo = c0; if (w < lo) lo = w over corners 1..7 -- a NaN in
-                // corner 0 stays (every comparison with it is false), a NaN elsewhere is skipped: fmin / fmax skip NaNs everywhere.
-                // Lane k < 3 takes coordinate k: the region is the box c0' = lo, edges (hi - lo) along the axes.
-                const double c0k = C[0][k % 3];
-                const double mine = C[k][0], miney = C[k][1], minez = C[k][2];
-                const double l0 = lpf_min8(mine), h0 = lpf_max8(mine), l1 = lpf_min8(miney), h1 = lpf_max8(miney), l2 = lpf_min8(minez), h2 = lpf_max8(minez);
-                double lo = (k % 3 == 0) ? l0 : (k % 3 == 1) ? l1 : l2, hi = (k % 3 == 0) ? h0 : (k % 3 == 1) ? h1 : h2;
-                if (!(c0k == c0k)) { lo = c0k; hi = c0k; }
-                if (live && k < 3) { J.boxp[gb * 16 + k] = on ? lo : 0.0; J.boxp[gb * 16 + 3 + k] = on ? hi : 0.0; }
-                if (live) { J.boxp[gb * 16 + 6 + k] = 0.0; if (k < 2) J.boxp[gb * 16 + 14 + k] = 0.0; }
-                __builtin_amdgcn_wave_barrier();            // every lane has read its corner
-                if (k < 3) {
-                    C[0][k] = lo;                           // origin of the region
-                    C[1 + k][0] = (k == 0) ? hi - lo : 0.0; C[1 + k][1] = (k == 1) ? hi - lo : 0.0; C[1 + k][2] = (k == 2) ? hi - lo : 0.0;
-                }
-                if (__popcll(__ballot(k < 3 && (!isfinite(lo) || !isfinite(hi))) & gmask) != 0) bounded = false;
-                __builtin_amdgcn_wave_barrier();
-            }
-            // ---- phase 4, lanes 0..2 = coordinate: conservative float bounds of the region c0 + s0 e0 + s1 e1 + s2 e2, s in [0,1]^3 ----
-            {
-                bool fin = true;
-                if (k < 3) {
-                    const double c0k = C[0][k], e0 = C[1][k], e1 = C[2][k], e2 = C[3][k];
-                    const double lov = c0k + fmin(e0, 0.0) + fmin(e1, 0.0) + fmin(e2, 0.0), hiv = c0k + fmax(e0, 0.0) + fmax(e1, 0.0) + fmax(e2, 0.0);
-                    fin = isfinite(lov) && isfinite(hiv);
-                    C[4][k] = lov; C[5][k] = hiv;
-                }
-                if (__popcll(__ballot(!fin) & gmask) != 0) bounded = false;
-                __builtin_amdgcn_wave_barrier();
-                if (live && k < 6) {                        // {lo xyz, -, hi xyz, -}: lanes 0..2 lo, 3..5 hi
-                    const int kk = k % 3;
-                    const double lov = C[4][kk], hiv = C[5][kk];
-                    float q;
-                    if (!on) q = (k < 3) ? INFINITY : -INFINITY;                      // empty: nothing is near
-                    else if (!bounded) q = (k < 3) ? -INFINITY : INFINITY;
-                    else {
-                        const double m = 1e-5 * (fabs(lov) + fabs(hiv) + (hiv - lov)) + 1e-6;
-                        q = (k < 3) ? nextafterf((float)(lov - m), -INFINITY) : nextafterf((float)(hiv + m), INFINITY);
-                    }
-                    J.boxq[gb * 8 + (k < 3 ? k : k + 1)] = q;
-                }
-                if (live && k >= 6) J.boxq[gb * 8 + (k == 6 ? 3 : 7)] = 0.f;
-            }
-            // ---- phase 5, lane = vertex of the region: the image of the 8 vertices bounds the image of the region ---------------
-            bool everywhere = !bounded;
-            double u, w;
-            {
-                const double s0f = (k & 1) ? 1.0 : 0.0, s1f = (k & 2) ? 1.0 : 0.0, s2f = (k & 4) ? 1.0 : 0.0;
-                const double px = C[0][0] + s0f * C[1][0] + s1f * C[2][0] + s2f * C[3][0];
-                const double py = C[0][1] + s0f * C[1][1] + s1f * C[2][1] + s2f * C[3][1];
-                const double pz = C[0][2] + s0f * C[1][2] + s1f * C[2][2] + s2f * C[3][2];
-                const double cx = J.T[0] * px + J.T[1] * py + J.T[2] * pz + J.T[3];
-                const double cy = J.T[4] * px + J.T[5] * py + J.T[6] * pz + J.T[7];
-                const double cz = J.T[8] * px + J.T[9] * py + J.T[10] * pz + J.T[11];
-                const double qx = J.K[0] * cx + J.K[1] * cy + J.K[2] * cz;
-                const double qy = J.K[3] * cx + J.K[4] * cy + J.K[5] * cz;
-                const double d = J.K[6] * cx + J.K[7] * cy + J.K[8] * cz;
-                const bool bad = !(d > 1e-3) || !isfinite(qx) || !isfinite(qy);
-                if (__popcll(__ballot(bad) & gmask) != 0) everywhere = true;
-                u = qx / d; w = qy / d;
-            }
-            double umin = lpf_min8(u), umax = lpf_max8(u), vmin = lpf_min8(w), vmax = lpf_max8(w);
-            int x0 = 0, x1 = J.cell_w - 1, y0 = 0, y1 = J.cell_h - 1;
-            if (!everywhere) {
-                umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;                // rounding of (u, v) + slack
-                if (umax < 0 || vmax < 0 || umin > J.W || vmin > J.H) { x0 = 1; x1 = 0; }       // never seen by a valid point
-                else {
-                    x0 = umin <= 0 ? 0 : (int)umin >> J.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> J.cell_shift;
-                    x1 = umax >= J.W ? J.cell_w - 1 : (int)umax >> J.cell_shift; y1 = vmax >= J.H ? J.cell_h - 1 : (int)vmax >> J.cell_shift;
-                    x1 = min(x1, J.cell_w - 1); y1 = min(y1, J.cell_h - 1);
-                }
-            }
-            if (!on) { x0 = 1; x1 = 0; }
-            if (live && k == 0) {
-                short *r = L.rect[b - s0];
-                r[0] = (short)x0; r[1] = (short)x1; r[2] = (short)y0; r[3] = (short)y1;
-            }
-            __builtin_amdgcn_wave_barrier();                // the slots are rewritten by the next pass
-        }
+    const int words = (bf.B + 63) >> 6;
+    if (wd >= words) return;
+    const int b_lo = wd << 6, B = min(bf.B, b_lo + 64);     // this block's boxes: [b_lo, B)
+    // ---- word wd of every cell of the frame's grid starts empty: plain stores by this block, which is also the only one to
+    //      set bits in that word below (same CU, same L2: ordered by the barrier) -- no memset launch in front, nothing to clean
+    //      afterwards ----------------------------------------------------------------------------------------------------------
+    unsigned long long *__restrict__ gf = J.cand + bf.cand_off + wd;
+    {
+        const int ncell = J.cell_w * J.cell_h;
+        int t0_ = tid;
+        asm volatile("" : "+v"(t0_));
+        for (int i = t0_; i < ncell; i += LPF_BLOCK) gf[(size_t)i * words] = 0ull;
+        __threadfence_block();
         __syncthreads();
-        // ---- gather: word w of cell (cx, cy) = the boxes 64 w .. 64 w + 63 whose rectangle holds the cell ------------------
-        const int ncell = J.cell_w * J.cell_h, w0 = s0 >> 6, w1 = (s1 + 63) >> 6, nw = w1 - w0;
-        unsigned long long *__restrict__ gf = J.cand + bf.cand_off;
-        int t2_ = tid;
-        asm volatile("" : "+v"(t2_));
-        for (int i = t2_; i < ncell * nw; i += LPF_BLOCK) {
-            const int cell = i / nw, wd = w0 + (i - cell * nw);
-            const int cy = cell / J.cell_w, cx = cell - cy * J.cell_w;
-            unsigned long long bits = 0ull;
-            const int be = min(64, B - (wd << 6));
-            for (int j = 0; j < be; ++j) {
-                const short *r = L.rect[(wd << 6) + j - s0];                      // every lane reads the same entry: a broadcast
-                const int rx0 = r[0], rx1 = r[1], ry0 = r[2], ry1 = r[3];
-                if (cx >= rx0 && cx <= rx1 && cy >= ry0 && cy <= ry1) bits |= 1ull << j;
+    }
+    for (int b0 = b_lo; b0 < B; b0 += 32) {
+        // (everything that depends on the thread index is derived again in every pass, behind an empty asm: hoisted out of
+        //  the loop, those loop invariants -- addresses, selectors, constants -- cost more registers than the work itself)
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int grp = t_ >> 3, k = t_ & 7;
+        const unsigned long long gmask = 0xFFull << (t_ & 56);
+        double (*C)[3] = L.c[grp];                          // the box's 8 slots of 3 doubles: corners first, then reused (see below)
+        const int b = b0 + grp;
+        const bool live = b < B;
+        const size_t gb = (size_t)bf.box_off + (size_t)(live ? b : 0);
+        // ---- phase 1, lane = corner: to the velodyne frame (and, cam-0 input, the visibility of the box) -----------------
+        bool on = true;
+        {
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (live) { const double *cc = J.src + (gb * 8 + k) * 3; x = cc[0]; y = cc[1]; z = cc[2]; }
+            if (J.cam0) {
+                // cam2image on the raw cam-0 corners, WITHOUT R_rect (reference quirk, V3:129-138)
+                double qx = J.K[0] * x; qx = fma(J.K[1], y, qx); qx = fma(J.K[2], z, qx);
+                double qy = J.K[3] * x; qy = fma(J.K[4], y, qy); qy = fma(J.K[5], z, qy);
+                double d  = J.K[6] * x; d  = fma(J.K[7], y, d);  d  = fma(J.K[8], z, d);
+                if (d == 0.0) d = -1e-6;
+                double uf, vf;
+                lpf_div2(qx, qy, fabs(d), uf, vf);          // both quotients as '/' gives them (see lpf_div2)
+                const double ru = rint(uf), rv = rint(vf);
+                const bool in_img = (ru >= 0.0) && (ru < (double)J.W) && (rv >= 0.0) && (rv < (double)J.H);
+                const bool vis = live && (d > 0.1) && in_img;
+                const bool frn = live && (d > 0.0);
+                const int nvis = __popcll(__ballot(vis) & gmask), nfront = __popcll(__ballot(frn) & gmask);
+                on = !J.filter_visible || nvis >= 2;
+                if (J.bbox2d) {                             // V4:157-168: min / max of the integer (u, v) over the corners in front
+                    const double umin = lpf_min8(frn ? ru : 1e300), umax = lpf_max8(frn ? ru : -1e300);
+                    const double vmin = lpf_min8(frn ? rv : 1e300), vmax = lpf_max8(frn ? rv : -1e300);
+                    if (live && k == 0) { J.bbox2d[4 * gb] = umin; J.bbox2d[4 * gb + 1] = vmin; J.bbox2d[4 * gb + 2] = umax; J.bbox2d[4 * gb + 3] = vmax; }
+                }
+                if (live && k == 0) {
+                    if (J.visible) J.visible[gb] = (uint8_t)(nvis >= 2);
+                    if (J.front) J.front[gb] = nfront;
+                    if (J.enabled_out) J.enabled_out[gb] = (uint8_t)(nvis >= 2);
+                }
+                // transform_bboxes_to_velodyne (V3:41-52): rows of inv(TrVeloToCam) as k-ordered fma chains
+                double a0 = J.Tcv[0] * x; a0 = fma(J.Tcv[1], y, a0); a0 = fma(J.Tcv[2],  z, a0); a0 = fma(J.Tcv[3],  1.0, a0);
+                double a1 = J.Tcv[4] * x; a1 = fma(J.Tcv[5], y, a1); a1 = fma(J.Tcv[6],  z, a1); a1 = fma(J.Tcv[7],  1.0, a1);
+                double a2 = J.Tcv[8] * x; a2 = fma(J.Tcv[9], y, a2); a2 = fma(J.Tcv[10], z, a2); a2 = fma(J.Tcv[11], 1.0, a2);
+                x = a0; y = a1; z = a2;
+            } else if (J.enabled_in) {
+                on = !live || J.enabled_in[gb] != 0;
             }
-            gf[(size_t)cell * words + wd] = bits;
+            if (live) {
+                if (J.corners_keep) { double *o = J.corners_keep + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
+                if (J.corners_out) { double *o = J.corners_out + (gb * 8 + k) * 3; o[0] = x; o[1] = y; o[2] = z; }
+            }
+            C[k][0] = x; C[k][1] = y; C[k][2] = z;
         }
-        __syncthreads();                                    // the rectangles are rewritten by the next pass
+        __builtin_amdgcn_wave_barrier();                    // the 8 lanes of a box are lanes of one wave: its LDS queue is in order
+        bool bounded = true;
+        if (J.oriented) {
+            // ---- phase 2, lanes 1..3 = slab a: v_a = c_{1,3,4} - c0, |v_a|^2 -- the exact parameters (V3:187-197) -----------
+            bool ok = true;
+            if (k >= 1 && k <= 3) {
+                const int a = k - 1, oc = (a == 0) ? 1 : (a == 1) ? 3 : 4;
+                const double v0 = C[oc][0] - C[0][0], v1 = C[oc][1] - C[0][1], v2 = C[oc][2] - C[0][2];
+                double w = v0 * v0; w = fma(v1, v1, w); w = fma(v2, v2, w);
+                ok = (w >= 1e-100 && w <= 1e100);           // also false for NaN (see lpf_oriented_inside)
+                if (live) {
+                    double *o = J.boxp + gb * 16 + 3 + 4 * a;
+                    o[0] = on ? v0 : 0.0; o[1] = on ? v1 : 0.0; o[2] = on ? v2 : 0.0; o[3] = on ? w : 0.0;
+                }
+                C[5 + a][0] = v0; C[5 + a][1] = v1; C[5 + a][2] = v2;           // corners 5..7 are not needed any more
+                asm volatile("" ::: "memory");
+                C[4][a] = w;                                // (slab 2 has read corner 4: in-order LDS queue of the wave)
+            }
+            ok = __popcll(__ballot(!ok) & gmask) == 0;
+            if (live && k == 0) {
+                double *o = J.boxp + gb * 16;
+                o[0] = on ? C[0][0] : 0.0; o[1] = on ? C[0][1] : 0.0; o[2] = on ? C[0][2] : 0.0; o[15] = (on && ok) ? 1.0 : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase 3, lanes 0..2 = edge a of the region { p : 0 <= (p - c0) . v_a <= |v_a|^2 }: with w_a the reciprocal
+            //      basis (w_a . v_b = delta_ab), e_a = |v_a|^2 w_a, w_a = (v_b x v_c) / det, (a, b, c) cyclic -------------------
+            bool good = true;
+            if (k < 3) {
+                const int a = k, bb = (a + 1) % 3, cc = (a + 2) % 3;
+                const double bx = C[5 + bb][0], by = C[5 + bb][1], bz = C[5 + bb][2];
+                const double cx = C[5 + cc][0], cy = C[5 + cc][1], cz = C[5 + cc][2];
+                const double nx = by * cz - bz * cy, ny = bz * cx - bx * cz, nz = bx * cy - by * cx;
+                const double det = C[5 + a][0] * nx + C[5 + a][1] * ny + C[5 + a][2] * nz;
+                const double r = C[4][a] * lpf_rcp_approx(det);
+                const double ex = nx * r, ey = ny * r, ez = nz * r;
+                // well-conditioned: |det| > 1e-6 |v0| |v1| |v2|, compared as squares (no square root)
+                good = (det * det > 1e-12 * (C[4][0] * C[4][1] * C[4][2])) && (ex == ex) && (ey == ey) && (ez == ez);
+                C[1 + a][0] = ex; C[1 + a][1] = ey; C[1 + a][2] = ez;           // corners 1..3 have been read
+            }
+            if (!ok || __popcll(__ballot(!good) & gmask) != 0) bounded = false;
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // point_in_bbox (V3:158-162) as the oracle restates it: lo = c0; if (w < lo) lo = w over corners 1..7 -- a NaN in
+            // corner 0 stays (every comparison with it is false), a NaN elsewhere is skipped: fmin / fmax skip NaNs everywhere.
+            // Lane k < 3 takes coordinate k: the region is the box c0' = lo, edges (hi - lo) along the axes.
+            const double c0k = C[0][k % 3];
+            const double mine = C[k][0], miney = C[k][1], minez = C[k][2];
+            const double l0 = lpf_min8(mine), h0 = lpf_max8(mine), l1 = lpf_min8(miney), h1 = lpf_max8(miney), l2 = lpf_min8(minez), h2 = lpf_max8(minez);
+            double lo = (k % 3 == 0) ? l0 : (k % 3 == 1) ? l1 : l2, hi = (k % 3 == 0) ? h0 : (k % 3 == 1) ? h1 : h2;
+            if (!(c0k == c0k)) { lo = c0k; hi = c0k; }
+            if (live && k < 3) { J.boxp[gb * 16 + k] = on ? lo : 0.0; J.boxp[gb * 16 + 3 + k] = on ? hi : 0.0; }
+            if (live) { J.boxp[gb * 16 + 6 + k] = 0.0; if (k < 2) J.boxp[gb * 16 + 14 + k] = 0.0; }
+            __builtin_amdgcn_wave_barrier();                // every lane has read its corner
+            if (k < 3) {
+                C[0][k] = lo;                               // origin of the region
+                C[1 + k][0] = (k == 0) ? hi - lo : 0.0; C[1 + k][1] = (k == 1) ? hi - lo : 0.0; C[1 + k][2] = (k == 2) ? hi - lo : 0.0;
+            }
+            if (__popcll(__ballot(k < 3 && (!isfinite(lo) || !isfinite(hi))) & gmask) != 0) bounded = false;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- phase 4, lanes 0..2 = coordinate: conservative float bounds of the region c0 + s0 e0 + s1 e1 + s2 e2, s in [0,1]^3.
+        //      The margin (1e-5 relative + 1e-6) is far above the float rounding of the conversion, so no next-float step. ------
+        {
+            bool fin = true;
+            if (k < 3) {
+                const double c0k = C[0][k], e0 = C[1][k], e1 = C[2][k], e2 = C[3][k];
+                const double lov = c0k + fmin(e0, 0.0) + fmin(e1, 0.0) + fmin(e2, 0.0), hiv = c0k + fmax(e0, 0.0) + fmax(e1, 0.0) + fmax(e2, 0.0);
+                fin = isfinite(lov) && isfinite(hiv);
+                const double m = 1e-5 * (fabs(lov) + fabs(hiv) + (hiv - lov)) + 1e-6;
+                C[4][k] = lov - m; C[5][k] = hiv + m;
+            }
+            if (__popcll(__ballot(!fin) & gmask) != 0) bounded = false;
+            __builtin_amdgcn_wave_barrier();
+            if (live) {                                     // {lo xyz, 0, hi xyz, 0}: lane k writes float k
+                const int kk = k & 3;
+                float q = 0.f;
+                if (kk < 3) {
+                    if (!on) q = (k < 4) ? INFINITY : -INFINITY;                      // empty: nothing is near
+                    else if (!bounded) q = (k < 4) ? -INFINITY : INFINITY;
+                    else q = (float)C[k < 4 ? 4 : 5][kk];
+                }
+                J.boxq[gb * 8 + k] = q;
+            }
+        }
+        // ---- phase 5, lane = vertex of the region: the image of the 8 vertices bounds the image of the region ---------------
+        bool everywhere = !bounded;
+        double u, w;
+        {
+            const double s0f = (k & 1) ? 1.0 : 0.0, s1f = (k & 2) ? 1.0 : 0.0, s2f = (k & 4) ? 1.0 : 0.0;
+            const double px = C[0][0] + s0f * C[1][0] + s1f * C[2][0] + s2f * C[3][0];
+            const double py = C[0][1] + s0f * C[1][1] + s1f * C[2][1] + s2f * C[3][1];
+            const double pz = C[0][2] + s0f * C[1][2] + s1f * C[2][2] + s2f * C[3][2];
+            const double cx = J.T[0] * px + J.T[1] * py + J.T[2] * pz + J.T[3];
+            const double cy = J.T[4] * px + J.T[5] * py + J.T[6] * pz + J.T[7];
+            const double cz = J.T[8] * px + J.T[9] * py + J.T[10] * pz + J.T[11];
+            const double qx = J.K[0] * cx + J.K[1] * cy + J.K[2] * cz;
+            const double qy = J.K[3] * cx + J.K[4] * cy + J.K[5] * cz;
+            const double d = J.K[6] * cx + J.K[7] * cy + J.K[8] * cz;
+            const bool bad = !(d > 1e-3) || !isfinite(qx) || !isfinite(qy);
+            if (__popcll(__ballot(bad) & gmask) != 0) everywhere = true;
+            const double rd = lpf_rcp_approx(d);
+            u = qx * rd; w = qy * rd;
+        }
+        double umin = lpf_min8(u), umax = lpf_max8(u), vmin = lpf_min8(w), vmax = lpf_max8(w);
+        int x0 = 0, x1 = J.cell_w - 1, y0 = 0, y1 = J.cell_h - 1;
+        if (!everywhere) {
+            umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;                    // rounding of (u, v) + slack
+            if (umax < 0 || vmax < 0 || umin > J.W || vmin > J.H) { x0 = 1; x1 = 0; }           // never seen by a valid point
+            else {
+                x0 = umin <= 0 ? 0 : (int)umin >> J.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> J.cell_shift;
+                x1 = umax >= J.W ? J.cell_w - 1 : (int)umax >> J.cell_shift; y1 = vmax >= J.H ? J.cell_h - 1 : (int)vmax >> J.cell_shift;
+                x1 = min(x1, J.cell_w - 1); y1 = min(y1, J.cell_h - 1);
+            }
+        }
+        // ---- the box's bit into every cell of its rectangle: the 8 lanes of the box share the cells -------------------------------
+        if (live && on && x0 <= x1) {
+            const int nx = x1 - x0 + 1, nc = nx * (y1 - y0 + 1);
+            const unsigned long long bit = 1ull << (b & 63);
+            for (int i = k; i < nc; i += 8) {
+                const int yy = y0 + i / nx, xx = x0 + i % nx;
+                atomicOr(&gf[(size_t)(yy * J.cell_w + xx) * words], bit);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                    // the slots are rewritten by the next pass
     }
 }
 
