@@ -258,8 +258,8 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     }
     const int nk1_pad = (Y.nk1 + 7) & ~7;
     Y.nper = (Y.ntail + 7) / 8;
-    Y.kper = 8;
-    if (Y.nper > 0) {                                      // spread the tail blocks over the first two thirds of the tiles (same box,
+    Y.kper = Y.nk1 > 0 ? 8 : 0;                            // (a drain launch without tiles: the tail blocks alone, no empty tile slots)
+    if (Y.nper > 0 && Y.nk1 > 0) {                                      // spread the tail blocks over the first two thirds of the tiles (same box,
         // us per step at 40 / 50 / 60 / 70 / 80 / 90 %: 105.6 / 103-105.6 / 99.5-101.6 / 100.3-101.1 / 101.8-102.3 / 102.3-102.5;
         // again with the pack riding, 40 / 50 / 65 / 80 / 95 %: 95.4 / 95.6-95.9 / 91.4-92.0 / 93.2-93.3 / 93.9:
         // early enough that the last tail blocks do not outlive the tiles, late enough not to crowd the start)

@@ -888,8 +888,12 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
 // AABB of the region first, the survivors are queued per wave and take the reference's f64 test a whole wave at a
 // time.  Hits are counted in the block's LDS counters and flushed once per block.
 // ------------------------------------------------------------------------------------
-#define LPF_BC_LDSCNT 1024        // LDS inside-counters: M * B up to this many (else one global atomic per hit)
-#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS (their float bounds: 64)
+#define LPF_BC_LDSCNT 2048        // LDS inside-counters: M * B up to this many (else one global atomic per hit); 16 bits each, two per
+                                  // word: a block counts at most 4 x 4096 points per (mask, box), so a half never carries
+#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS
+#define LPF_BC_LDSQ 320           // ... and whose float bounds (24 bytes each).  Frames of the sample carry up to 314 annotated boxes; with
+                                  // only 64 staged, every further candidate cost a dependent read from memory inside the candidate loop
+                                  // (a chunk of 64 masked points of such a frame: ~30 us)
 
 // row prefixes of a segment's masked ballots: lane r -> entries in rows 0..r (im) and before row r (mbase); returns the total
 __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned &im, unsigned &mbase)
@@ -915,7 +919,8 @@ __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const Lpf
 // one chunk of 64 masked points (entries e0 .. e0+63 of segment sid, L in all) against the frame's candidate boxes
 __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFrame &fr, const int sid, const unsigned im, const unsigned mbase,
                                                 const unsigned L, const unsigned e0, float4 *s_pt, unsigned *qq, unsigned *s_cnt,
-                                                const bool lds_cnt, const float4 *s_bq, const double *s_bp, const double *s_tk)
+                                                const bool lds_cnt, const float *s_bq, const double *s_bp, const double *s_tk,
+                                                const int ldsb, const int w_lo, const int w_hi)
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -934,11 +939,11 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
             int in;                                         // (LDS first, the rare box beyond it from memory afterwards: see below)
             {
-                const double *bp = s_bp + (b & (LPF_BC_LDSB - 1)) * 16;
+                const double *bp = s_bp + min(b, ldsb - 1) * 16;
                 in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
             }
             asm volatile("" : "+v"(in));
-            if (b >= LPF_BC_LDSB) {
+            if (b >= ldsb) {
                 const double *bp = boxp + (size_t)b * 16;
                 in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
             }
@@ -947,8 +952,9 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
                 while (l) {
                     const int m = __ffs(l) - 1;
                     l &= l - 1;
-                    if (lds_cnt) atomicAdd(&s_cnt[m * B + b], 1u);
-                    else atomicAdd(&cnt[m * B + b], 1u);
+                    const int ci = m * B + b;
+                    if (lds_cnt) atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                    else atomicAdd(&cnt[ci], 1u);
                 }
             }
         }
@@ -978,7 +984,7 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
         cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
     }
     const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
-    for (int w = 0; w < fr.cand_words; ++w) {
+    for (int w = w_lo; w < w_hi; ++w) {                    // (the candidate words are independent of each other: one box, one bit, one counter)
         unsigned long long mset = act ? cg[w] : 0ull;
         while (__any(mset != 0ull)) {
             const bool has = mset != 0ull;
@@ -988,9 +994,10 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
             if (has) {
                 // (an LDS read, then a rare read from memory, kept apart by the empty asm: written as a choice between the two
                 //  pointers it compiles to flat loads -- and cost lpf_step_t two spilled registers)
-                float4 lo = s_bq[2 * (b & 63)], hi = s_bq[2 * (b & 63) + 1];
+                const float *sq = s_bq + 6 * min(b, LPF_BC_LDSQ - 1);
+                float4 lo = make_float4(sq[0], sq[1], sq[2], 0.f), hi = make_float4(sq[3], sq[4], sq[5], 0.f);
                 asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
-                if (b >= 64) { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
+                if (b >= LPF_BC_LDSQ) { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
                 near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
             }
             const unsigned long long bal = __ballot(near);
@@ -1015,12 +1022,12 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
 
 // a wave takes a whole segment (big sparse launches: a chunk or so per segment)
 __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
-                                                  unsigned *s_cnt, const bool lds_cnt, const float4 *s_bq, const double *s_bp,
+                                                  unsigned *s_cnt, const bool lds_cnt, const float *s_bq, const double *s_bp,
                                                   const double *s_tk)
 {
     unsigned im, mbase;
     const unsigned L = lpf_count_rows(P, fr, sid, im, mbase);
-    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, lds_cnt, s_bq, s_bp, s_tk);
+    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, lds_cnt, s_bq, s_bp, s_tk, LPF_BC_LDSB, 0, fr.cand_words);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1030,7 +1037,7 @@ __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfF
 // ------------------------------------------------------------------------------------
 #define LPF_SUMMARY_BYTES 928
 
-#define LPF_FIN_STAGE 1024        // inside counts staged in LDS (M x B up to this many: one memory round trip for everything)
+#define LPF_FIN_STAGE 2048        // inside counts staged in LDS (M x B up to this many: one memory round trip for everything)
 
 __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const LpfFrame &fr, const int f, unsigned *s_tot, unsigned *s_c)
 {
@@ -1143,8 +1150,8 @@ struct LpfTailListsLds { unsigned short lidx[LPF_LISTS_WAVES][LPF_LIST_CAP]; }; 
 struct LpfTailCountLds {
     float4 pt[LPF_LISTS_WAVES][64];           // xyz + label of a wave's current chunk
     unsigned q[LPF_LISTS_WAVES][128];         // (point, box) pairs that passed the float bounds
-    unsigned cnt[LPF_BC_LDSCNT];              // the block's inside counts [M][B]
-    float4 bq[2 * 64];                        // {lo, hi} float bounds of the frame's boxes 0..63
+    unsigned cnt[LPF_BC_LDSCNT / 2];          // the block's inside counts [M][B], 16 bits each
+    float bq[6 * LPF_BC_LDSQ];                // {lo xyz, hi xyz} float bounds of the frame's boxes 0..LPF_BC_LDSQ-1
     double bp[LPF_BC_LDSB * 16];              // exact parameters of boxes 0..LPF_BC_LDSB-1
     double tk[21];                            // T (12) and K (9)
 };
@@ -1169,11 +1176,12 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     } else {
         const int MB = P.M * fr.B;
         const bool lds_cnt = MB <= LPF_BC_LDSCNT;
-        if (lds_cnt) for (int i = tid; i < MB; i += LPF_BLOCK) LC.cnt[i] = 0u;
+        if (lds_cnt) for (int i = tid; i < (MB + 1) >> 1; i += LPF_BLOCK) LC.cnt[i] = 0u;
         {   // box data of the frame and the camera constants -> LDS (one round trip for the block, issued before anything else)
             const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
             const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-            if (tid < 2 * min(fr.B, 64)) LC.bq[tid] = boxq[tid];
+            const float *__restrict__ bqf = reinterpret_cast<const float *>(boxq);      // 8 floats per box: {lo xyz, -, hi xyz, -}
+            for (int i = tid; i < min(fr.B, LPF_BC_LDSQ) * 6; i += LPF_BLOCK) { const int bx = i / 6, j = i - 6 * bx; LC.bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
             for (int i = tid; i < min(fr.B, LPF_BC_LDSB) * 16; i += LPF_BLOCK) LC.bp[i] = boxp[i];
             if (tid < 12) LC.tk[tid] = P.T[tid];
             else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
@@ -1184,7 +1192,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
         unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
         if (lds_cnt) {
             for (int i = tid; i < MB; i += LPF_BLOCK) {
-                const unsigned v = LC.cnt[i];
+                const unsigned v = (LC.cnt[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 if (v) atomicAdd(&cnt[i], v);
             }
         }
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
 // kept apart (lpf_count_chunk); before that it needed 72, and forced to 64 it spilled six registers per thread to scratch
 // -- HBM traffic too.  16.7 KB LDS.
 template <bool PRE>
-__global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
+__global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_TAIL_LDS];
     lpf_tail_block<PRE, 1>(P, (int)blockIdx.x, s_raw);
@@ -1210,13 +1218,14 @@ __global__ __launch_bounds__(LPF_BLOCK, 8) void lpf_tail_t(const LpfParams P)
 // waves (a segment each), the others leave at once.  Same results as lpf_tail_t.
 // ------------------------------------------------------------------------------------
 #define LPF_WIDE_WAVES 16
+#define LPF_BC_LDSB_WIDE 192      // boxes whose exact parameters a wide block keeps in LDS (24 KB of its 62)
 
 struct LpfTailWideLds {
     float4 pt[LPF_WIDE_WAVES][64];
     unsigned q[LPF_WIDE_WAVES][128];
-    unsigned cnt[LPF_BC_LDSCNT];
-    float4 bq[2 * 64];
-    double bp[LPF_BC_LDSB * 16];
+    unsigned cnt[LPF_BC_LDSCNT / 2];
+    float bq[6 * LPF_BC_LDSQ];
+    double bp[LPF_BC_LDSB_WIDE * 16];         // (few blocks per launch: room for the exact parameters of many boxes)
     double tk[21];
     unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];
 };
@@ -1238,12 +1247,13 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     }
     const int MB = P.M * fr.B;
     const bool lds_cnt = MB <= LPF_BC_LDSCNT;
-    if (lds_cnt) for (int i = tid; i < MB; i += 64 * LPF_WIDE_WAVES) LC.cnt[i] = 0u;
+    if (lds_cnt) for (int i = tid; i < (MB + 1) >> 1; i += 64 * LPF_WIDE_WAVES) LC.cnt[i] = 0u;
     {
         const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
         const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-        if (tid < 2 * min(fr.B, 64)) LC.bq[tid] = boxq[tid];
-        for (int i = tid; i < min(fr.B, LPF_BC_LDSB) * 16; i += 64 * LPF_WIDE_WAVES) LC.bp[i] = boxp[i];
+        const float *__restrict__ bqf = reinterpret_cast<const float *>(boxq);
+        for (int i = tid; i < min(fr.B, LPF_BC_LDSQ) * 6; i += 64 * LPF_WIDE_WAVES) { const int bx = i / 6, j = i - 6 * bx; LC.bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
+        for (int i = tid; i < min(fr.B, LPF_BC_LDSB_WIDE) * 16; i += 64 * LPF_WIDE_WAVES) LC.bp[i] = boxp[i];
         if (tid < 12) LC.tk[tid] = P.T[tid];
         else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
     }
@@ -1256,17 +1266,21 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     __syncthreads();
     const unsigned L0 = LC.L[0], L1 = LC.L[1], L2 = LC.L[2], L3 = LC.L[3];
     const int c0 = (int)((L0 + 63) >> 6), c1 = (int)((L1 + 63) >> 6), c2 = (int)((L2 + 63) >> 6), c3 = (int)((L3 + 63) >> 6);
-    for (int c = wave; c < c0 + c1 + c2 + c3; c += LPF_WIDE_WAVES) {      // wave-uniform: chunk c of the block -> (segment, chunk of it)
+    // work unit = (chunk, candidate word): a frame with many boxes has several 64-box words per cell, each with its own candidates and
+    // its own exact tests -- independent work that the 16 waves share as they share the chunks
+    const int nwords = fr.cand_words;
+    for (int u = wave; u < (c0 + c1 + c2 + c3) * nwords; u += LPF_WIDE_WAVES) {      // wave-uniform: unit u -> (segment, chunk of it, word)
+        const int c = u / nwords, wd = u - c * nwords;
         int sg = 0, cc = c;
         if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
         lpf_count_chunk(P, fr, ent.x + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
-                        LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
+                        LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, LPF_BC_LDSB_WIDE, wd, wd + 1);
     }
     __syncthreads();
     unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
     if (lds_cnt) {
         for (int i = tid; i < MB; i += 64 * LPF_WIDE_WAVES) {
-            const unsigned v = LC.cnt[i];
+            const unsigned v = (LC.cnt[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
             if (v) atomicAdd(&cnt[i], v);
         }
     }

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""146 real frames per step (the four full-size golden frames in turn, ~16.9 M points): in-order steps for a kernel trace.
+usage: rocprofv3 --kernel-trace --stats ... -- python3 tools/real_probe.py [serial|fused|fused-pack] [noboxes|nolists|nomasks] [frames]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "serial"
+lab = sys.argv[2] if len(sys.argv) > 2 else ""
+nfr = int(sys.argv[3]) if len(sys.argv) > 3 else 146
+dev = torch.device("cuda", 0)
+gdir = os.path.join(ROOT, "tests", "golden")
+cal = np.load(os.path.join(gdir, "calib_cam0.npz"))
+T, K, W, H = np.asarray(cal["TrVeloToRect"]), np.asarray(cal["K"])[:3, :3], int(cal["width"]), int(cal["height"])
+Tcv = np.linalg.inv(np.asarray(cal["TrVeloToCam"]))
+frames = []
+for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002098_full.npz", "frame_0000002449_full.npz"):
+    g = np.load(os.path.join(gdir, name))
+    frames.append(dict(points=np.ascontiguousarray(g["points"], dtype=np.float32),
+                       masks=np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :W].astype(np.uint8),
+                       cam0=np.ascontiguousarray(g["corners_cam0_raw"], dtype=np.float64)))
+batch = [frames[i % 4] for i in range(nfr)]
+sizes = [len(f["points"]) for f in batch]
+off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+boff = np.concatenate([[0], np.cumsum([len(f["cam0"]) for f in batch])]).astype(np.int32)
+M, ntot, cap = 5, int(off[-1]), max(sizes)
+d_pts = torch.from_numpy(np.concatenate([f["points"] for f in batch])).to(dev)
+d_masks = torch.from_numpy(np.stack([f["masks"] for f in batch])).to(dev)
+d_cam0 = torch.from_numpy(np.concatenate([f["cam0"] for f in batch])).to(dev)
+o = dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(ntot, dtype=torch.int32, device=dev),
+         valid_idx=None if lab == "nolists" else torch.empty(ntot, dtype=torch.int64, device=dev),
+         inst_idx=None if lab == "nolists" else torch.empty((nfr, cap), dtype=torch.int64, device=dev),
+         count_mb=torch.zeros(M * int(boff[-1]), dtype=torch.int32, device=dev), summary=torch.zeros(nfr * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+torch.cuda.synchronize(dev)
+with LpfContext(0) as ctx:
+    ctx.set_pipelined(False if mode == "serial" else mode)
+    ctx.set_camera(T, K, W, H, 0.0, 50.0)
+    fn = ctx.make_device_step(d_pts, off, masks_u8=None if lab == "nomasks" else d_masks, lend=True, boxes_cam0=None if lab == "noboxes" else d_cam0,
+                              box_off=boff, T_cam_to_velo=Tcv, inst_cap=cap, **o)
+    for _ in range(5):
+        fn()
+    ctx.sync()
+    t0 = time.perf_counter()
+    reps = 30
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    print("%s %s frames=%d points=%d: %.1f us per step" % (mode, lab or "all", nfr, ntot, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
+    sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+    print("valid %d masked %d list entries %d" % (sm["n_valid"].sum(), sm["n_labelled"].sum(), sm["inst_count"].sum()))
