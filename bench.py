@@ -464,10 +464,14 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         frame_work()
         gr = ctx.graph_end()
         lat = []
+        t_next = time.perf_counter()
         for i in range(nframes + 4):
             sc = scs[i % len(scs)]
-            load(sc)
-            time.sleep(0.002)                                # a sensor does not deliver frames back to back
+            load(sc)                                         # (the "sensor": a multi-threaded 16 MB host copy into pinned memory)
+            t_next += 0.010                                  # frames are paced (100 Hz here, 10 x the sensor's rate): back to back, the host
+            d_ = t_next - time.perf_counter()                # copies alone exhaust a CPU-quota'd container's CFS period and the process
+            if d_ > 0:                                       # is throttled for tens of ms with the GPU idle (tools/stream_latency.py)
+                time.sleep(d_)
             t0 = time.perf_counter()
             ctx.graph_launch(gr)
             ctx.sync()
@@ -483,8 +487,8 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         lat = 1e3 * np.array(lat[4:])
         out["configs4_stream_hipgraph_per_frame"] = {
             "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "p99_ms": float(np.percentile(lat, 99)),
-            "max_ms": float(lat.max()),
-            "frames": int(len(lat)), "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "boxes_change_every_frame": True,
+            "max_ms": float(lat.max()), "frames_over_1ms": int((lat > 1.0).sum()),
+            "frames": int(len(lat)), "paced_hz": 100, "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "boxes_change_every_frame": True,
             "budget_ms_at_10Hz": 100.0,
             "includes": "H2D of points + masks + box corners (pinned), box table set-up, mask pack + erosion, project+label, lists + box counts, "
                         "finalize, D2H of counts + summary",

@@ -36,15 +36,51 @@ def needs_build(lib=None):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def torch_lib_dir():
+    """Directory of the HIP runtime the PyTorch-ROCm wheel bundles (libamdhip64.so), or None."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        tl = os.path.join(os.path.dirname(spec.origin), "lib") if spec and spec.origin else None
+    except Exception:
+        tl = None
+    return tl if tl and os.path.exists(os.path.join(tl, "libamdhip64.so")) else None
+
+
 def build(force=False, verbose=False, lab=False):
-    """liblpf.so (the product), or with lab=True liblpf_lab.so: the same sources compiled with -DLPF_LAB."""
+    """liblpf.so (the product), or with lab=True liblpf_lab.so: the same sources compiled with -DLPF_LAB.
+
+    A process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own copy and its libraries ask for it by the
+    name ``libamdhip64.so``; /opt/rocm's carries the SONAME ``libamdhip64.so.7``, which is what a plain hipcc link records.
+    The loader takes those for two different libraries: a liblpf.so linked the plain way and loaded BEFORE torch left the
+    process with both runtimes, and torch then failed with "No HIP GPUs are available".  So the library is linked in two
+    steps: compile, then link against a stub that carries the SONAME ``libamdhip64.so`` (only the name is recorded), with an
+    RPATH of torch's lib directory (if torch is installed) and /opt/rocm/lib.  Whichever of liblpf.so and torch is loaded
+    first, the other finds the runtime already mapped under the name it asks for."""
     lib = LAB_LIB if lab else LIB
     if not force and not needs_build(lib):
         return lib
-    cmd = [hipcc()] + FLAGS + (["-DLPF_LAB"] if lab else []) + ["-o", lib, os.path.join(CSRC, "lpf_api.hip")]
+    work = os.path.join(_HERE, "build", "lab" if lab else "lib")
+    os.makedirs(os.path.join(work, "stub"), exist_ok=True)
+    obj = os.path.join(work, "lpf_api.o")
+    compile_flags = [f for f in FLAGS if f not in ("-shared", "-pthread", "-ldl")]
+    cmds = [[hipcc()] + compile_flags + (["-DLPF_LAB"] if lab else []) + ["-c", os.path.join(CSRC, "lpf_api.hip"), "-o", obj]]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(cmds[0]))
+    subprocess.check_call(cmds[0], cwd=CSRC)
+    undefined = subprocess.run(["nm", "-u", obj], check=True, capture_output=True, text=True).stdout.split()
+    names = sorted({n for n in undefined if n.startswith(("hip", "__hip"))})
+    stub_c = os.path.join(work, "stub", "stub.c")
+    with open(stub_c, "w") as f:
+        f.write("/* link-time stand-in for the HIP runtime: only its SONAME is recorded in liblpf.so */\n")
+        f.write("".join("void %s(void) {}\n" % n for n in names))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-Wl,-soname,libamdhip64.so", stub_c, "-o", os.path.join(work, "stub", "libamdhip64.so")])
+    rpath = ":".join([d for d in (torch_lib_dir(), "/opt/rocm/lib") if d])
+    link = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-no-hip-rt", obj, "-L" + os.path.join(work, "stub"), "-lamdhip64",
+            "-Wl,-rpath," + rpath, "-Wl,--disable-new-dtags", "-pthread", "-ldl", "-o", lib]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
     return lib
 
 

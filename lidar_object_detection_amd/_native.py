@@ -243,6 +243,7 @@ class LpfContext:
         self.F_masks = 0
         self.box_off = None
         self._depth = 1
+        self._pin = {}                          # persistent page-locked host buffers (run_batch(pinned=True))
         # lent tensors (masks, box corners) of the runs that may still read them: in the pipelined modes a run's inputs are read
         # up to two launches after it was queued, so the references of the last few runs are kept (torch's caching allocator is
         # ordered with torch's stream, not with this context's)
@@ -544,12 +545,24 @@ class LpfContext:
         """One frame of f32[N,4] host points -> dict of NumPy results (see run_batch)."""
         return self.run_batch([points], **kw)[0]
 
+    def _pinned(self, name, shape, dtype):
+        """A persistent page-locked host array of the context (grow-only): copies from the GPU into it are DMA transfers the
+        call does not stage through pageable memory, and a frame loop does not allocate (and page in) megabytes per call."""
+        import torch
+        need = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = self._pin.get(name)
+        if buf is None or buf.numel() < need:
+            buf = self._pin[name] = torch.empty(max(need + need // 4, 4096), dtype=torch.uint8).pin_memory()
+        return buf.numpy()[:need].view(dtype).reshape(shape)
+
     def run_batch(self, frames, want_uv=True, want_label=True, want_float=False, want_lists=True,
-                  inst_cap=None, want_valid_uv=False):
+                  inst_cap=None, want_valid_uv=False, pinned=False):
         """frames: list of f32[N_f,4] arrays.  Returns one dict per frame with
         u, v (int32), label_bits, valid_idx, inst_lists, inst_count, count_mb, best_box, best_cnt,
         n_valid, n_labelled (+ depth, uf, vf with want_float; + u_valid, v_valid, label_valid with
-        want_valid_uv: the values at the valid points only -- with want_uv/want_label off, a quarter of the read-back)."""
+        want_valid_uv: the values at the valid points only -- with want_uv/want_label off, a quarter of the read-back).
+        pinned=True: the result arrays are views into page-locked buffers the context owns and reuses -- valid until the next
+        run on this context (copy what must live longer); the frame loops use it."""
         scan = frames[0] if (len(frames) == 1 and isinstance(frames[0], Scan)) else None
         if scan is not None:                     # points already in HBM (ScanReader): no host staging
             frames = [scan.points]
@@ -569,20 +582,23 @@ class LpfContext:
         Btot = int(self.box_off[-1]) if self.box_off is not None else 0
         if inst_cap is None:
             inst_cap = max(int(max(p.shape[0] for p in frames)), 1)
+        new = (lambda name, shape, dt: self._pinned(name, shape, dt)) if pinned else (lambda name, shape, dt: np.empty(shape, dt))
         while True:
             o = Outputs()
             o.on_device = 0
-            uv = np.empty((n, 2), np.int32) if want_uv else None
-            lab = np.empty(n, np.uint32) if want_label else None
-            dep = np.empty(n, np.float64) if want_float else None
-            uf = np.empty(n, np.float64) if want_float else None
-            vf = np.empty(n, np.float64) if want_float else None
-            vidx = np.empty(n, np.int64) if want_lists else None
-            uvv = np.empty((n, 2), np.int32) if (want_valid_uv and want_lists) else None     # only the first n_valid rows come back
-            labv = np.empty(n, np.uint32) if (want_valid_uv and want_lists) else None
-            iidx = np.empty((F, inst_cap), np.int64) if (want_lists and M) else None
-            cmb = np.zeros(max(M * Btot, 1), np.int32)
-            summ = np.zeros(F, SUMMARY_DTYPE)
+            uv = new("uv", (n, 2), np.int32) if want_uv else None
+            lab = new("lab", (n,), np.uint32) if want_label else None
+            dep = new("dep", (n,), np.float64) if want_float else None
+            uf = new("uf", (n,), np.float64) if want_float else None
+            vf = new("vf", (n,), np.float64) if want_float else None
+            vidx = new("vidx", (n,), np.int64) if want_lists else None
+            uvv = new("uvv", (n, 2), np.int32) if (want_valid_uv and want_lists) else None     # only the first n_valid rows come back
+            labv = new("labv", (n,), np.uint32) if (want_valid_uv and want_lists) else None
+            iidx = new("iidx", (F, inst_cap), np.int64) if (want_lists and M) else None
+            cmb = new("cmb", (max(M * Btot, 1),), np.int32)
+            cmb[:] = 0
+            summ = new("summ", (F,), SUMMARY_DTYPE)
+            summ.view(np.uint8)[:] = 0
             for name, arr in (("uv", uv), ("label_bits", lab), ("depth", dep), ("u_f", uf), ("v_f", vf),
                               ("valid_idx", vidx), ("inst_idx", iidx), ("count_mb", cmb), ("summary", summ),
                               ("uv_valid", uvv), ("label_valid", labv)):

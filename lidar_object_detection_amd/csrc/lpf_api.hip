@@ -621,7 +621,11 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera must be called before masks (W, H)");
-    if (F < 0 || M < 0 || M > LPF_MAX_MASKS || erode_iters < 0 || (F > 0 && M > 0 && !masks))
+    if (M > LPF_MAX_MASKS)
+        return fail(c, LPF_ERR_ARG, "set_masks: M=%d masks per frame, a run takes at most LPF_MAX_MASKS = %d (one bit each in label_bits): run the frame "
+                                    "once per group of %d masks -- everything per point is the same in every pass (pipeline.run_frames does so)",
+                    M, LPF_MAX_MASKS, LPF_MAX_MASKS);
+    if (F < 0 || M < 0 || erode_iters < 0 || (F > 0 && M > 0 && !masks))
         return fail(c, LPF_ERR_ARG, "set_masks: F=%d M=%d erode_iters=%d masks=%p", F, M, erode_iters, (const void *)masks);
     // software-pipelined modes + device masks: the label images rotate with the scratch sets (the tiles of the previous run may
     // still have to read theirs); anything else uses set 0, with nothing owed

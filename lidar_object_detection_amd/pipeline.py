@@ -704,7 +704,11 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     stacks = [_mask_stack(f.masks if f.masks is not None else [], camera) for f in frames]
     M = max(s.shape[0] for s in stacks)
     if M > LPF_MAX_MASKS:
-        raise NotImplementedError("more than %d detections in one frame" % LPF_MAX_MASKS)
+        # The reference loops over every mask (V3:220), with no bound; a launch labels a point with one bit per mask in a
+        # 32-bit word.  More detections than that: the frames run once per group of 32 masks (same points, same boxes) and the
+        # per-detection results are put together -- everything per point (pixels, valid indices) is the same in every pass.
+        return _run_frames_in_mask_groups(frames, stacks, TrVeloToRect, camera, depth_max, min_points, use_oriented, erode_iters,
+                                          v3_pipeline, device, ctx)
     on_gpu = [_is_device_tensor(s) for s in stacks]
     if any(on_gpu):                                                      # YOLO's masks still on the GPU: no host round trip
         import torch
@@ -730,11 +734,12 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline, lend=True)   # (the run follows in this call: GPU masks can be lent)
     ctx.set_boxes(corners, oriented=use_oriented)
     # only the valid points' pixels and labels are used below: fetch those (a quarter of the dense arrays on real frames)
-    res = ctx.run_batch([f.points for f in frames], want_uv=False, want_label=False, want_valid_uv=True)
+    # (results arrive in page-locked buffers the context reuses: what is handed to the caller is copied out of them below)
+    res = ctx.run_batch([f.points for f in frames], want_uv=False, want_label=False, want_valid_uv=True, pinned=True)
     out = []
     for f, r, s, pos in zip(frames, res, stacks, positions):
         m = s.shape[0]
-        vi = r["valid_idx"]
+        vi = r["valid_idx"].copy()
         host_pts = f.points.points if isinstance(f.points, Scan) else f.points     # Scan: pinned copy of the file
         pts_valid = host_pts[vi, :3]
         sets = [host_pts[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in r["inst_lists"][:m]]
@@ -745,8 +750,30 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
                 d.pop("_best_col"), d.pop("_best_count")
         out.append(dict(frame=f.frame, valid_indices=vi, u_valid=r["u_valid"].astype(np.int64), v_valid=r["v_valid"].astype(np.int64),
                         points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_valid"] != 0,
-                        count_mb=r["count_mb"][:m], car_statistics=stats, n_valid=r["n_valid"]))
+                        count_mb=r["count_mb"][:m].copy(), car_statistics=stats, n_valid=r["n_valid"]))
     return out
+
+
+def _run_frames_in_mask_groups(frames, stacks, TrVeloToRect, camera, depth_max, min_points, use_oriented, erode_iters, v3_pipeline,
+                               device, ctx):
+    """run_frames for frames with more than LPF_MAX_MASKS detections: one pass per group of 32 masks, results merged."""
+    M = max(s.shape[0] for s in stacks)
+    merged = None
+    for g0 in range(0, M, LPF_MAX_MASKS):
+        part = [FrameInputs(f.frame, f.points, s[g0:g0 + LPF_MAX_MASKS], f.bboxes_3d, f.colors[g0:g0 + LPF_MAX_MASKS], f.boxes_2d)
+                for f, s in zip(frames, stacks)]
+        res = run_frames(part, TrVeloToRect, camera, depth_max, min_points, use_oriented, erode_iters, v3_pipeline, device, ctx)
+        if merged is None:
+            merged = res
+            continue
+        for acc, r in zip(merged, res):
+            acc["car_point_sets"] += r["car_point_sets"]
+            acc["bg_assigned"] = acc["bg_assigned"] | r["bg_assigned"]
+            acc["count_mb"] = np.concatenate([acc["count_mb"], r["count_mb"]], axis=0)
+            for d in r["car_statistics"]:
+                d["car_id"] += g0                            # car ids count the detections of the whole frame (V3:330)
+            acc["car_statistics"] += r["car_statistics"]
+    return merged
 
 
 def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,

@@ -49,3 +49,34 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
         assert "HIP" in str(e) or "device" in str(e)
     else:
         raise AssertionError("LpfContext() succeeded without a GPU")
+
+
+_ORDER_SNIPPET = """
+import ctypes, sys
+{first}
+{second}
+maps = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
+print("RUNTIMES", len(maps), maps)
+{gpu}
+"""
+
+
+def _run_order(first, second, gpu=""):
+    import subprocess
+    import sys
+    lib = _native.library_path()
+    code = _ORDER_SNIPPET.format(first=first.format(lib=lib), second=second.format(lib=lib), gpu=gpu)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=REPO, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_one_hip_runtime_whichever_is_loaded_first():
+    """liblpf.so and PyTorch-ROCm in one process, in both load orders, through raw ctypes (no Python wrapper to put them in
+    order): exactly one libamdhip64 may end up mapped.  (ABI <= 4 was linked against /opt/rocm's SONAME and, loaded first, left
+    the process with two runtimes -- torch then reported "No HIP GPUs are available".)"""
+    _build.build()
+    load_lpf, load_torch = 'lib = ctypes.CDLL("{lib}")', "import torch"
+    for first, second in ((load_lpf, load_torch), (load_torch, load_lpf)):
+        out = _run_order(first, second)
+        assert "RUNTIMES 1 " in out, out

@@ -603,3 +603,49 @@ def test_run_frames_with_masks_that_stay_on_the_gpu(calib):
     assert np.array_equal(a["count_mb"], b["count_mb"]) and np.array_equal(a["valid_indices"], b["valid_indices"])
     assert all(np.array_equal(x, y) for x, y in zip(a["car_point_sets"], b["car_point_sets"]))
     assert np.array_equal(a["bg_assigned"], b["bg_assigned"])
+
+
+@pytest.mark.parametrize("order", ["liblpf_first", "torch_first"])
+def test_both_load_orders_work_on_the_gpu(order):
+    """Raw ctypes user of the C ABI and PyTorch in one process, liblpf.so loaded before or after torch: both must then be able
+    to use the GPU (one HIP runtime, see tests/test_abi_exports.py)."""
+    import subprocess
+    import sys
+    from lidar_object_detection_amd import _native
+    lib = _native.library_path()
+    load_lpf = 'import ctypes; lib = ctypes.CDLL("%s")' % lib
+    use = ('ctx = ctypes.c_void_p(); lib.lpf_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]\n'
+           'rc = lib.lpf_create(ctypes.byref(ctx), 0); assert rc == 0, rc\n'
+           'assert torch.cuda.is_available(); x = torch.arange(8, device="cuda").sum().item(); assert x == 28\n'
+           'lib.lpf_sync.argtypes = [ctypes.c_void_p]; assert lib.lpf_sync(ctx) == 0\n'
+           'lib.lpf_destroy.argtypes = [ctypes.c_void_p]; lib.lpf_destroy(ctx); print("OK")')
+    code = (load_lpf + "\nimport torch\n" if order == "liblpf_first" else "import torch\n" + load_lpf + "\n") + use
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_more_than_32_detections_in_a_frame(calib):
+    """The reference loops over every mask (V3:220), however many: run_frames takes 40 detections in two passes of the kernels
+    (32 + 8) and returns what one unbounded pass would -- per-detection point sets, counts and statistics in detection order."""
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    cam = _camera(calib)
+    sc = S.scene(90_000, n_masks=40, n_boxes=12, seed=4242, calib=calib)
+    masks = sc["masks"].astype(np.float32)
+    boxes = [{"corners_velo": c.tolist()} for c in sc["corners_velo"]]
+    r = pipeline.run_frames([pipeline.FrameInputs(7, sc["points"], masks, boxes)], calib["TrVeloToRect"], cam, 50.0, 10, True)[0]
+    assert len(r["car_point_sets"]) == 40 and r["count_mb"].shape == (40, 12)
+    any_mask = np.zeros(len(r["valid_indices"]), bool)
+    for g0 in (0, 32):
+        grp = sc["masks"][g0:g0 + 32]
+        o = orc.run(sc["points"], T, K, W, H, 0.0, 50.0, label_img=orc.pack_masks(grp, 0, H, W), M=len(grp), corners=sc["corners_velo"],
+                    want_float=False)
+        assert np.array_equal(r["valid_indices"], o["valid_idx"])
+        assert np.array_equal(r["count_mb"][g0:g0 + len(grp)], o["count_mb"])
+        for m in range(len(grp)):
+            assert np.array_equal(r["car_point_sets"][g0 + m], sc["points"][o["inst_lists"][m], :3])
+        any_mask |= o["label_bits"][o["valid_idx"]] != 0
+    assert np.array_equal(r["bg_assigned"], any_mask)
+    ids = [d["car_id"] for d in r["car_statistics"]]
+    assert ids == sorted(ids) and all(0 <= i < 40 for i in ids) and len(set(ids)) == len(ids)
+    assert [d["total_points"] for d in r["car_statistics"]] == [len(r["car_point_sets"][i]) for i in ids]

@@ -1,14 +1,15 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from lidar_object_detection_amd import synthetic as S
-from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+from lidar_object_detection_amd import _build
+from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE      # forced geometries: the lab build (python -m lidar_object_detection_amd._build lab)
 _, T, K, W, H = S.default_calibration()
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 scs = [S.scene(n, 8, 32, seed=7000 + i) for i in range(6)]
 stream = torch.cuda.Stream(dev)
 for geo in ("small", "small-narrow", "large"):
-    with torch.cuda.stream(stream), LpfContext(0) as ctx:
+    with torch.cuda.stream(stream), LpfContext(0, library=_build.LAB_LIB) as ctx:
         ctx.set_stream(stream.cuda_stream); ctx.set_geometry(geo)
         ctx.set_camera(T, K, W, H, 0.0, 30.0); ctx.set_boxes(scs[0]["corners_velo"])
         fns = []
@@ -17,7 +18,7 @@ for geo in ("small", "small-narrow", "large"):
                      valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty(n, dtype=torch.int64, device=dev),
                      count_mb=torch.zeros(8 * 32, dtype=torch.int32, device=dev), summary=torch.zeros(928, dtype=torch.uint8, device=dev))
             fns.append(ctx.make_device_step(torch.from_numpy(sc["points"]).to(dev), np.array([0, n], np.int64),
-                                            masks_u8=torch.from_numpy(sc["masks"][None]).to(dev), inst_cap=n, **o))
+                                            masks_u8=torch.from_numpy(sc["masks"][None]).to(dev), lend=True, inst_cap=n, **o))
         for f in fns: f()
         stream.synchronize()
         t0 = time.perf_counter()
