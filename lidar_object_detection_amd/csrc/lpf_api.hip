@@ -109,7 +109,7 @@ struct lpf_ctx {
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
         DevBuf tab;                   // [frames | segs | blks]
         std::vector<LpfFrame> tab_frames;         // the frame table `tab` holds (empty: none)
-        size_t o_segs = 0, o_blks = 0;
+        size_t o_segs = 0, o_blks = 0, o_cblks = 0;
     } sc[LPF_NSETS];
     int parity = 0;
     long long run_seq = 0;            // runs queued so far
@@ -1026,10 +1026,11 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // tail blocks: four consecutive segments of one frame each (an empty frame still gets one, to write its summary);
     // the list blocks, then -- when boxes are to be counted -- as many box-count blocks
     const bool count_boxes = M > 0 && Btot > 0;
-    int nblk = 0;
+    int nblk = 0, ncblk = 0;                               // list blocks; box-count blocks: one per group of segments and 64-box word
     for (int f = 0; f < F; ++f) {
         const int nb = c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
         nblk += nb;
+        ncblk += nb * std::max(1, c->h_frames[f].cand_words);
     }
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
     // a list wave sums one group's segments and the frame's groups, a lane each: frames of more than 64 groups
@@ -1054,22 +1055,32 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     //      when the batch shape does, and then travel through the pinned ring: no wait, no drain ---------------------------
     const bool have_tab = S.tab_frames.size() == (size_t)F && memcmp(S.tab_frames.data(), c->h_frames.data(), (size_t)F * sizeof(LpfFrame)) == 0;
     if (F > 1 && !have_tab) {
-        const size_t b_frames = (size_t)F * sizeof(LpfFrame), b_segs = (size_t)nseg_total * sizeof(LpfFrame), b_blks = (size_t)nblk * sizeof(int2);
-        if ((rc = reserve(c, S.tab, b_frames + b_segs + b_blks))) return rc;
-        c->h_tab.resize(b_frames + b_segs + b_blks);
+        const size_t b_frames = (size_t)F * sizeof(LpfFrame), b_segs = (size_t)nseg_total * sizeof(LpfFrame), b_blks = (size_t)nblk * sizeof(int2),
+                     b_cblks = (size_t)ncblk * sizeof(int4);
+        if ((rc = reserve(c, S.tab, b_frames + b_segs + b_blks + b_cblks))) return rc;
+        c->h_tab.resize(b_frames + b_segs + b_blks + b_cblks);
         memcpy(c->h_tab.data(), c->h_frames.data(), b_frames);
         LpfFrame *hs = reinterpret_cast<LpfFrame *>(c->h_tab.data() + b_frames);
         int2 *hb = reinterpret_cast<int2 *>(c->h_tab.data() + b_frames + b_segs);
+        int4 *hc = reinterpret_cast<int4 *>(c->h_tab.data() + b_frames + b_segs + b_blks);
         for (int f = 0; f < F; ++f) {
             const LpfFrame &fr = c->h_frames[f];
+            const int wpg = std::max(1, fr.cand_words);
             for (int sg = 0; sg < fr.nseg; ++sg) hs[(size_t)fr.seg_off + sg] = fr;
-            if (fr.nseg == 0) *hb++ = make_int2(fr.seg_off, f << 3);
-            for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES) *hb++ = make_int2(fr.seg_off + sg, (f << 3) | std::min(LPF_LISTS_WAVES, fr.nseg - sg));
+            if (fr.nseg == 0) {
+                *hb++ = make_int2(fr.seg_off, f << 3);
+                for (int w = 0; w < wpg; ++w) *hc++ = make_int4(fr.seg_off, f, w, 0);
+            }
+            for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES) {
+                const int nw = std::min(LPF_LISTS_WAVES, fr.nseg - sg);
+                *hb++ = make_int2(fr.seg_off + sg, (f << 3) | nw);
+                for (int w = 0; w < wpg; ++w) *hc++ = make_int4(fr.seg_off + sg, f, w, nw);
+            }
         }
         S.tab_frames.clear();                              // (nothing valid if the upload fails half way)
         if ((rc = upload(c, S.tab.p, c->h_tab.data(), c->h_tab.size()))) return rc;
         S.tab_frames = c->h_frames;
-        S.o_segs = b_frames; S.o_blks = b_frames + b_segs;
+        S.o_segs = b_frames; S.o_blks = b_frames + b_segs; S.o_cblks = b_frames + b_segs + b_blks;
         ++c->generation;                  // graphs captured for another geometry read these tables
     }
 
@@ -1085,6 +1096,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         P.frames = (const LpfFrame *)S.tab.p;
         P.segs = (const LpfFrame *)((const char *)S.tab.p + S.o_segs);
         P.blks = (const int2 *)((const char *)S.tab.p + S.o_blks);
+        P.cblks = (const int4 *)((const char *)S.tab.p + S.o_cblks);
     }
     // lent masks of a pipelined context (lpf_ctx::Ride): a small fused launch reads them directly, a large one in mode 4 carries
     // their pack, anything else (mode 2, float masks, a host-memory run) packs them now
@@ -1111,7 +1123,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.cnt = (unsigned *)S.cnt.p;
-    P.nblk = nblk; P.count_boxes = count_boxes ? 1 : 0;
+    P.nblk = nblk; P.ncblk = ncblk; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -1171,7 +1183,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
     const int lb = (M > 0) ? SM.label_bytes : 4;
     const bool want_lists = out->valid_idx || out->inst_idx;
-    const int ntail = nblk * ((count_boxes ? 1 : 0) + (want_lists ? 1 : 0));      // no lists wanted and no boxes: no tail blocks at all
+    const int ntail = (count_boxes ? ncblk : 0) + (want_lists ? nblk : 0);        // no lists wanted and no boxes: no tail blocks at all
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // mode 4: the mask pack and the tiles of one launch share the label element type -- else the pipeline is drained first
     if (fused && c->defer && c->pend_k1.valid && ride_pack && (c->pend_k1.direct || c->pend_k1.lb != lb) && (rc = flush_pending(c))) return rc;

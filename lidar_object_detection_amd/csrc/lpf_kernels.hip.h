@@ -58,8 +58,9 @@ struct LpfParams {
     LpfFrame frame0;             // the frame table by value when F == 1 (no dependent load)
     const LpfFrame *frames;      // [F]
     const LpfFrame *segs;        // [nseg_total] the owning frame's record per segment (pad = frame id)
-    const int2 *blks;            // [nblk] tail block table: {first segment, frame << 3 | segments (0..4)}
-    int nblk;
+    const int2 *blks;            // [nblk] list blocks of the tail: {first segment, frame << 3 | segments (0..4)}
+    const int4 *cblks;           // [ncblk] box-count blocks: {first segment, frame, candidate word, segments (0..4)}
+    int nblk, ncblk;
     const float4 *pts;
     const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
     const double *boxp;          // [Btot][16] exact box parameters
@@ -888,12 +889,11 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
 // AABB of the region first, the survivors are queued per wave and take the reference's f64 test a whole wave at a
 // time.  Hits are counted in the block's LDS counters and flushed once per block.
 // ------------------------------------------------------------------------------------
-#define LPF_BC_LDSCNT 2048        // LDS inside-counters: M * B up to this many (else one global atomic per hit); 16 bits each, two per
-                                  // word: a block counts at most 4 x 4096 points per (mask, box), so a half never carries
-#define LPF_BC_LDSB 32            // boxes whose exact parameters a block keeps in LDS
-#define LPF_BC_LDSQ 320           // ... and whose float bounds (24 bytes each).  Frames of the sample carry up to 314 annotated boxes; with
-                                  // only 64 staged, every further candidate cost a dependent read from memory inside the candidate loop
-                                  // (a chunk of 64 masked points of such a frame: ~30 us)
+#define LPF_BC_WORD 64            // boxes of a box-count block: ONE 64-box word of its frame's candidate grid.  A frame with more boxes gets a
+                                  // block per word (and 4 segments): each keeps its 64 boxes' float bounds (24 bytes each), exact parameters
+                                  // (128 bytes each) and inside counters (16 bits each, M x 64) in LDS -- whatever the frame's box count, the
+                                  // candidate loop and the exact tests never read box data from memory.  (With the frame's first 64 / 32 boxes
+                                  // staged and the rest read from memory, a chunk of 64 masked points of a 314-box frame took ~30 us.)
 
 // row prefixes of a segment's masked ballots: lane r -> entries in rows 0..r (im) and before row r (mbase); returns the total
 __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned &im, unsigned &mbase)
@@ -916,45 +916,32 @@ __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const Lpf
     return lpf_rl(im, 63);
 }
 
-// one chunk of 64 masked points (entries e0 .. e0+63 of segment sid, L in all) against the frame's candidate boxes
+// one chunk of 64 masked points (entries e0 .. e0+63 of segment sid, L in all) against candidate word wd of the frame's grid:
+// boxes 64 wd .. 64 wd + 63, whose bounds / exact parameters / counters the block holds in LDS under their index in the word
 __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFrame &fr, const int sid, const unsigned im, const unsigned mbase,
                                                 const unsigned L, const unsigned e0, float4 *s_pt, unsigned *qq, unsigned *s_cnt,
-                                                const bool lds_cnt, const float *s_bq, const double *s_bp, const double *s_tk,
-                                                const int ldsb, const int w_lo, const int w_hi)
+                                                const float *s_bq, const double *s_bp, const double *s_tk, const int wd)
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int B = fr.B;
-    const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
-    const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
     const float4 *__restrict__ mseg = P.mlist + fr.pt_off + (size_t)(sid - fr.seg_off) * P.seg_pts;
     const int rows_per_wave = P.tile_pts >> 8;
     const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
     auto exact = [&](int count) {
         if (lane < count) {
             const unsigned ent = qq[lane];
-            const int e = (int)(ent & 63u), b = (int)(ent >> 6);
+            const int e = (int)(ent & 63u), j = (int)(ent >> 6);                    // point of the chunk, box of the word
             const float4 x = s_pt[e];
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
-            int in;                                         // (LDS first, the rare box beyond it from memory afterwards: see below)
-            {
-                const double *bp = s_bp + min(b, ldsb - 1) * 16;
-                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            }
-            asm volatile("" : "+v"(in));
-            if (b >= ldsb) {
-                const double *bp = boxp + (size_t)b * 16;
-                in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            }
+            const double *bp = s_bp + j * 16;
+            const bool in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
             if (in) {
                 unsigned l = __float_as_uint(x.w);
                 while (l) {
                     const int m = __ffs(l) - 1;
                     l &= l - 1;
-                    const int ci = m * B + b;
-                    if (lds_cnt) atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
-                    else atomicAdd(&cnt[ci], 1u);
+                    const int ci = m * LPF_BC_WORD + j;
+                    atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
                 }
             }
         }
@@ -983,36 +970,28 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
         lpf_project_point_mem(s_tk, p.x, p.y, p.z, uf, vf, d);
         cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
     }
-    const unsigned long long *__restrict__ cg = P.cand + fr.cand_off + (size_t)cell * fr.cand_words;
-    for (int w = w_lo; w < w_hi; ++w) {                    // (the candidate words are independent of each other: one box, one bit, one counter)
-        unsigned long long mset = act ? cg[w] : 0ull;
-        while (__any(mset != 0ull)) {
-            const bool has = mset != 0ull;
-            const int b = has ? (w << 6) + __ffsll((long long)mset) - 1 : 0;
-            mset &= mset - 1ull;
-            bool near = false;
-            if (has) {
-                // (an LDS read, then a rare read from memory, kept apart by the empty asm: written as a choice between the two
-                //  pointers it compiles to flat loads -- and cost lpf_step_t two spilled registers)
-                const float *sq = s_bq + 6 * min(b, LPF_BC_LDSQ - 1);
-                float4 lo = make_float4(sq[0], sq[1], sq[2], 0.f), hi = make_float4(sq[3], sq[4], sq[5], 0.f);
-                asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
-                if (b >= LPF_BC_LDSQ) { lo = boxq[2 * b]; hi = boxq[2 * b + 1]; }
-                near = p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
-            }
-            const unsigned long long bal = __ballot(near);
-            if (!bal) continue;
-            if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)b << 6);
-            qn += __popcll(bal);
-            if (qn >= 64) {
-                __builtin_amdgcn_wave_barrier();
-                exact(64);
-                const unsigned rest = qq[64 + lane];
-                __builtin_amdgcn_wave_barrier();
-                qq[lane] = rest;
-                qn -= 64;
-                __builtin_amdgcn_wave_barrier();
-            }
+    unsigned long long mset = act ? P.cand[fr.cand_off + (size_t)cell * fr.cand_words + wd] : 0ull;
+    while (__any(mset != 0ull)) {
+        const bool has = mset != 0ull;
+        const int j = has ? __ffsll((long long)mset) - 1 : 0;
+        mset &= mset - 1ull;
+        bool near = false;
+        if (has) {
+            const float *sq = s_bq + 6 * j;
+            near = p.x >= sq[0] && p.x <= sq[3] && p.y >= sq[1] && p.y <= sq[4] && p.z >= sq[2] && p.z <= sq[5];
+        }
+        const unsigned long long bal = __ballot(near);
+        if (!bal) continue;
+        if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)j << 6);
+        qn += __popcll(bal);
+        if (qn >= 64) {
+            __builtin_amdgcn_wave_barrier();
+            exact(64);
+            const unsigned rest = qq[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            qq[lane] = rest;
+            qn -= 64;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1022,12 +1001,36 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
 
 // a wave takes a whole segment (big sparse launches: a chunk or so per segment)
 __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
-                                                  unsigned *s_cnt, const bool lds_cnt, const float *s_bq, const double *s_bp,
-                                                  const double *s_tk)
+                                                  unsigned *s_cnt, const float *s_bq, const double *s_bp, const double *s_tk, const int wd)
 {
     unsigned im, mbase;
     const unsigned L = lpf_count_rows(P, fr, sid, im, mbase);
-    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, lds_cnt, s_bq, s_bp, s_tk, LPF_BC_LDSB, 0, fr.cand_words);
+    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, s_bq, s_bp, s_tk, wd);
+}
+
+// Box data of word wd of the frame (boxes 64 wd ..) and the camera constants -> LDS, the block's counters zeroed; and, after the
+// counting, the counters flushed into the frame's [M][B] counts.  nthr threads take part.
+__device__ __forceinline__ void lpf_count_stage(const LpfParams &P, const LpfFrame &fr, const int wd, const int tid, const int nthr,
+                                                unsigned *s_cnt, float *s_bq, double *s_bp, double *s_tk)
+{
+    const int b0 = wd * LPF_BC_WORD, nb = min(fr.B - b0, LPF_BC_WORD);
+    const float *__restrict__ bqf = P.boxq + ((size_t)fr.box_off + b0) * 8;          // 8 floats per box: {lo xyz, -, hi xyz, -}
+    const double *__restrict__ boxp = P.boxp + ((size_t)fr.box_off + b0) * 16;
+    for (int i = tid; i < (P.M * LPF_BC_WORD + 1) >> 1; i += nthr) s_cnt[i] = 0u;
+    for (int i = tid; i < nb * 6; i += nthr) { const int bx = i / 6, j = i - 6 * bx; s_bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
+    for (int i = tid; i < nb * 16; i += nthr) s_bp[i] = boxp[i];
+    if (tid < 12) s_tk[tid] = P.T[tid];
+    else if (tid < 21) s_tk[tid] = P.K[tid - 12];
+}
+__device__ __forceinline__ void lpf_count_flush(const LpfParams &P, const LpfFrame &fr, const int wd, const int tid, const int nthr, const unsigned *s_cnt)
+{
+    const int b0 = wd * LPF_BC_WORD, nb = min(fr.B - b0, LPF_BC_WORD);
+    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
+    for (int i = tid; i < P.M * LPF_BC_WORD; i += nthr) {
+        const int m = i / LPF_BC_WORD, j = i - m * LPF_BC_WORD;
+        const unsigned v = (s_cnt[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        if (v && j < nb) atomicAdd(&cnt[m * fr.B + b0 + j], v);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1137,66 +1140,65 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
 // counted -- count their segments' masked points into the boxes.  Neither half needs anything from the other, and
 // nothing waits inside the kernel.  lpf_finalize then writes the per-frame summaries.
 // ------------------------------------------------------------------------------------
-// Tail block table: {first segment, frame << 3 | segments (0..4)} of block i.  A launch of ONE frame needs no table (and so
-// no upload when its size changes from run to run): block i takes segments 4 i .. 4 i + 3 of frame 0.
+// Tail block tables.  List blocks: {first segment, frame << 3 | segments (0..4)} of block i.  Box-count blocks: {first segment,
+// frame, candidate word, segments} -- a group of four segments gets a count block per 64-box word of its frame.
+// A launch of ONE frame needs no table (and so no upload when its size changes from run to run): list block i takes segments
+// 4 i .. 4 i + 3, count block i is (group i / words, word i % words).
 __device__ __forceinline__ int2 lpf_tail_entry(const LpfParams &P, const int i)
 {
     if (P.F > 1) return P.blks[i];
     const int first = i * LPF_LISTS_WAVES;
     return make_int2(first, max(0, min(LPF_LISTS_WAVES, P.frame0.nseg - first)));
 }
+__device__ __forceinline__ void lpf_count_entry(const LpfParams &P, const int i, int &first, int &f, int &nw, int &wd)
+{
+    if (P.F > 1) {
+        const int4 e = P.cblks[i];
+        first = e.x; f = e.y; wd = e.z; nw = e.w;
+        return;
+    }
+    const int words = max(1, P.frame0.cand_words);
+    const int g = i / words;
+    wd = i - g * words; f = 0; first = g * LPF_LISTS_WAVES;
+    nw = max(0, min(LPF_LISTS_WAVES, P.frame0.nseg - first));
+}
 
 struct LpfTailListsLds { unsigned short lidx[LPF_LISTS_WAVES][LPF_LIST_CAP]; };            // masked entries of a pass
 struct LpfTailCountLds {
     float4 pt[LPF_LISTS_WAVES][64];           // xyz + label of a wave's current chunk
     unsigned q[LPF_LISTS_WAVES][128];         // (point, box) pairs that passed the float bounds
-    unsigned cnt[LPF_BC_LDSCNT / 2];          // the block's inside counts [M][B], 16 bits each
-    float bq[6 * LPF_BC_LDSQ];                // {lo xyz, hi xyz} float bounds of the frame's boxes 0..LPF_BC_LDSQ-1
-    double bp[LPF_BC_LDSB * 16];              // exact parameters of boxes 0..LPF_BC_LDSB-1
+    unsigned cnt[LPF_MAX_MASKS_DEV * LPF_BC_WORD / 2];     // the block's inside counts [M][64], 16 bits each
+    float bq[6 * LPF_BC_WORD];                // {lo xyz, hi xyz} float bounds of the word's boxes
+    double bp[LPF_BC_WORD * 16];              // their exact parameters
     double tk[21];                            // T (12) and K (9)
 };
 
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
 #define LPF_STEP_LDS (LPF_TAIL_LDS > sizeof(LpfBoxJobLds) ? LPF_TAIL_LDS : sizeof(LpfBoxJobLds))
 
-// one tail block: the first nblk count boxes (when there are any: the longer chain goes first), the next nblk build lists
+// one tail block: the first P.ncblk count boxes (when there are any: the longer chain goes first), the next P.nblk build lists
 template <bool PRE, int STEP>
 __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb, char *s_raw)
 {
     LpfTailListsLds &LL = *reinterpret_cast<LpfTailListsLds *>(s_raw);
     LpfTailCountLds &LC = *reinterpret_cast<LpfTailCountLds *>(s_raw);
     const int tid = threadIdx.x, wave = lpf_wave();
-    const int ncount = P.count_boxes ? P.nblk : 0;          // (the list blocks follow; none when no list is wanted)
-    const bool count_role = tb < ncount;
-    const int2 ent = lpf_tail_entry(P, count_role ? tb : tb - ncount);     // {first segment, frame << 3 | segments}
-    const int f = ent.y >> 3, nw = ent.y & 7;
-    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
-    if (!count_role) {
+    const int ncount = P.count_boxes ? P.ncblk : 0;         // (the list blocks follow; none when no list is wanted)
+    if (tb >= ncount) {
+        const int2 ent = lpf_tail_entry(P, tb - ncount);    // {first segment, frame << 3 | segments}
+        const int f = ent.y >> 3, nw = ent.y & 7;
+        const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
-    } else {
-        const int MB = P.M * fr.B;
-        const bool lds_cnt = MB <= LPF_BC_LDSCNT;
-        if (lds_cnt) for (int i = tid; i < (MB + 1) >> 1; i += LPF_BLOCK) LC.cnt[i] = 0u;
-        {   // box data of the frame and the camera constants -> LDS (one round trip for the block, issued before anything else)
-            const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
-            const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-            const float *__restrict__ bqf = reinterpret_cast<const float *>(boxq);      // 8 floats per box: {lo xyz, -, hi xyz, -}
-            for (int i = tid; i < min(fr.B, LPF_BC_LDSQ) * 6; i += LPF_BLOCK) { const int bx = i / 6, j = i - 6 * bx; LC.bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
-            for (int i = tid; i < min(fr.B, LPF_BC_LDSB) * 16; i += LPF_BLOCK) LC.bp[i] = boxp[i];
-            if (tid < 12) LC.tk[tid] = P.T[tid];
-            else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
-        }
-        __syncthreads();
-        if (wave < nw) lpf_boxcount_wave(P, fr, ent.x + wave, LC.pt[wave], LC.q[wave], LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk);
-        __syncthreads();
-        unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-        if (lds_cnt) {
-            for (int i = tid; i < MB; i += LPF_BLOCK) {
-                const unsigned v = (LC.cnt[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                if (v) atomicAdd(&cnt[i], v);
-            }
-        }
+        return;
     }
+    int first, f, nw, wd;
+    lpf_count_entry(P, tb, first, f, nw, wd);
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
+    lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.tk);
+    __syncthreads();
+    if (wave < nw) lpf_boxcount_wave(P, fr, first + wave, LC.pt[wave], LC.q[wave], LC.cnt, LC.bq, LC.bp, LC.tk, wd);
+    __syncthreads();
+    lpf_count_flush(P, fr, wd, tid, LPF_BLOCK, LC.cnt);
 }
 
 // 8 blocks per CU: 58 VGPRs since the frame record lives in scalar registers (lpf_frame_record) and the LDS / memory choices are
@@ -1218,14 +1220,13 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
 // waves (a segment each), the others leave at once.  Same results as lpf_tail_t.
 // ------------------------------------------------------------------------------------
 #define LPF_WIDE_WAVES 16
-#define LPF_BC_LDSB_WIDE 192      // boxes whose exact parameters a wide block keeps in LDS (24 KB of its 62)
 
 struct LpfTailWideLds {
     float4 pt[LPF_WIDE_WAVES][64];
     unsigned q[LPF_WIDE_WAVES][128];
-    unsigned cnt[LPF_BC_LDSCNT / 2];
-    float bq[6 * LPF_BC_LDSQ];
-    double bp[LPF_BC_LDSB_WIDE * 16];         // (few blocks per launch: room for the exact parameters of many boxes)
+    unsigned cnt[LPF_MAX_MASKS_DEV * LPF_BC_WORD / 2];
+    float bq[6 * LPF_BC_WORD];
+    double bp[LPF_BC_WORD * 16];
     double tk[21];
     unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];
 };
@@ -1236,54 +1237,35 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     __shared__ __attribute__((aligned(16))) char s_raw[sizeof(LpfTailWideLds)];
     LpfTailWideLds &LC = *reinterpret_cast<LpfTailWideLds *>(s_raw);
     const int tid = threadIdx.x, lane = lpf_lane(), wave = tid >> 6, tb = (int)blockIdx.x;
-    const int ncount = P.count_boxes ? P.nblk : 0;
-    const bool count_role = tb < ncount;
-    const int2 ent = lpf_tail_entry(P, count_role ? tb : tb - ncount);
-    const int f = ent.y >> 3, nw = ent.y & 7;
-    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
-    if (!count_role) {
+    const int ncount = P.count_boxes ? P.ncblk : 0;
+    if (tb >= ncount) {
+        const int2 ent = lpf_tail_entry(P, tb - ncount);
+        const int f = ent.y >> 3, nw = ent.y & 7;
+        const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);   // (this form: small launches only)
         return;
     }
-    const int MB = P.M * fr.B;
-    const bool lds_cnt = MB <= LPF_BC_LDSCNT;
-    if (lds_cnt) for (int i = tid; i < (MB + 1) >> 1; i += 64 * LPF_WIDE_WAVES) LC.cnt[i] = 0u;
-    {
-        const float4 *__restrict__ boxq = reinterpret_cast<const float4 *>(P.boxq) + (size_t)fr.box_off * 2;
-        const double *__restrict__ boxp = P.boxp + (size_t)fr.box_off * 16;
-        const float *__restrict__ bqf = reinterpret_cast<const float *>(boxq);
-        for (int i = tid; i < min(fr.B, LPF_BC_LDSQ) * 6; i += 64 * LPF_WIDE_WAVES) { const int bx = i / 6, j = i - 6 * bx; LC.bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
-        for (int i = tid; i < min(fr.B, LPF_BC_LDSB_WIDE) * 16; i += 64 * LPF_WIDE_WAVES) LC.bp[i] = boxp[i];
-        if (tid < 12) LC.tk[tid] = P.T[tid];
-        else if (tid < 21) LC.tk[tid] = P.K[tid - 12];
-    }
+    int first, f, nw, wd;
+    lpf_count_entry(P, tb, first, f, nw, wd);
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (wave < LPF_LISTS_WAVES) {                           // the block's (up to) four segments: row prefixes -> LDS
         unsigned im = 0, mbase = 0, L = 0;
-        if (wave < nw) L = lpf_count_rows(P, fr, ent.x + wave, im, mbase);
+        if (wave < nw) L = lpf_count_rows(P, fr, first + wave, im, mbase);
         LC.im[wave][lane] = im; LC.mbase[wave][lane] = mbase;
         if (lane == 0) LC.L[wave] = L;
     }
+    lpf_count_stage(P, fr, wd, tid, 64 * LPF_WIDE_WAVES, LC.cnt, LC.bq, LC.bp, LC.tk);
     __syncthreads();
     const unsigned L0 = LC.L[0], L1 = LC.L[1], L2 = LC.L[2], L3 = LC.L[3];
     const int c0 = (int)((L0 + 63) >> 6), c1 = (int)((L1 + 63) >> 6), c2 = (int)((L2 + 63) >> 6), c3 = (int)((L3 + 63) >> 6);
-    // work unit = (chunk, candidate word): a frame with many boxes has several 64-box words per cell, each with its own candidates and
-    // its own exact tests -- independent work that the 16 waves share as they share the chunks
-    const int nwords = fr.cand_words;
-    for (int u = wave; u < (c0 + c1 + c2 + c3) * nwords; u += LPF_WIDE_WAVES) {      // wave-uniform: unit u -> (segment, chunk of it, word)
-        const int c = u / nwords, wd = u - c * nwords;
+    for (int c = wave; c < c0 + c1 + c2 + c3; c += LPF_WIDE_WAVES) {      // wave-uniform: chunk c of the block -> (segment, chunk of it)
         int sg = 0, cc = c;
         if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
-        lpf_count_chunk(P, fr, ent.x + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
-                        LC.cnt, lds_cnt, LC.bq, LC.bp, LC.tk, LPF_BC_LDSB_WIDE, wd, wd + 1);
+        lpf_count_chunk(P, fr, first + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
+                        LC.cnt, LC.bq, LC.bp, LC.tk, wd);
     }
     __syncthreads();
-    unsigned *__restrict__ cnt = P.cnt + (size_t)P.M * fr.box_off;
-    if (lds_cnt) {
-        for (int i = tid; i < MB; i += 64 * LPF_WIDE_WAVES) {
-            const unsigned v = (LC.cnt[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            if (v) atomicAdd(&cnt[i], v);
-        }
-    }
+    lpf_count_flush(P, fr, wd, tid, 64 * LPF_WIDE_WAVES, LC.cnt);
 }
 
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""cvs_erosion.process_frames (cvs:298-379) end to end on a dataset tree rebuilt from the committed golden frames -- 20 frames: the
+four full-size ones (100, 1461, 2098, 2449), five times each under distinct frame numbers, with their deterministic masks as the
+"segmenter" -- timed as the package runs it (one batched call for all frames; and frame by frame with the read-ahead scan
+reader), beside the reference's NumPy statements for the same frames on the host (oracle/numpy_path.py: box preparation +
+projection + mask look-up + box counts).  File reading, JSON parsing and the CSV are part of both.  Prints one JSON line."""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch  # noqa: F401
+    from conftest import load_calib
+    from lidar_object_detection_amd import kitti360, pipeline
+    from oracle import numpy_path as npp
+    calib = load_calib()
+    W, H = int(calib["width"]), int(calib["height"])
+    cam = kitti360.CameraPerspective.from_arrays(calib["K"], calib["R_rect"], W, H)
+    K3, T = np.asarray(calib["K"])[:3, :3], np.asarray(calib["TrVeloToRect"])
+    seq = "2013_05_28_drive_0000_sync"
+    gdir = os.path.join(ROOT, "tests", "golden")
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "KITTI360_sample")
+        for d in (("data_3d_raw", seq, "velodyne_points", "data"), ("bboxes_3D_cam0",), ("data_2d_raw", seq, "image_00", "data_rect")):
+            os.makedirs(os.path.join(root, *d))
+        masks_of, frames = {}, []
+        for rep in range(5):
+            for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002098_full.npz", "frame_0000002449_full.npz"):
+                g = np.load(os.path.join(gdir, name))
+                fr = int(name.split("_")[1].split(".")[0]) + 10000 * rep
+                np.ascontiguousarray(g["points"], dtype=np.float32).tofile(os.path.join(root, "data_3d_raw", seq, "velodyne_points", "data", "%010d.bin" % fr))
+                open(os.path.join(root, "data_2d_raw", seq, "image_00", "data_rect", "%010d.png" % fr), "wb").close()
+                raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in enumerate(g["corners_cam0_raw"])]
+                json.dump(raw, open(os.path.join(root, "bboxes_3D_cam0", "BBoxes_%d.json" % fr), "w"))
+                masks_of[fr] = np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :W].astype(np.float32)
+                frames.append(fr)
+        velo = kitti360.Kitti360Viewer3DRaw(seq=0, root_dir=root)
+        pipeline.sequence_setup = lambda path, s=0, c=0: (seq, cam, calib["TrVeloToCam"], calib["TrVeloToRect"], velo)
+
+        def segmenter(image_path):
+            m = masks_of[int(os.path.basename(image_path).split(".")[0])]
+            return None, m, pipeline.default_colors(len(m)), np.zeros((len(m), 4), np.float32), np.ones(len(m))
+
+        def run(read_ahead, k):
+            csv = os.path.join(tmp, "results_%d_%d" % (read_ahead, k), "master.csv")
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                df = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=root, master_csv_path=csv,
+                                             timestamp="T", read_ahead=read_ahead)
+            return time.perf_counter() - t0, df
+
+        run(False, 0)                                       # warm (allocations)
+        t_batch, df = min((run(False, k) for k in range(1, 4)), key=lambda t: t[0])
+        t_ahead, df2 = min((run(True, k) for k in range(1, 4)), key=lambda t: t[0])
+        assert df.equals(df2) and len(df) > 50
+        # the reference's statements for the same frames, on the host
+        t0 = time.perf_counter()
+        rows = 0
+        for fr in sorted(frames):
+            pts = velo.loadVelodyneData(fr)
+            raw = kitti360.load_bounding_boxes(os.path.join(root, "bboxes_3D_cam0", "BBoxes_%d.json" % fr))
+            camc = np.array([b["corners_cam0"] for b in raw], np.float64)
+            keep, velo_c = npp.prepare_boxes(camc, K3, W, H, calib["TrVeloToCam"])
+            out = npp.frame_path(pts, T, K3, W, H, 50.0, masks_of[fr], velo_c[keep])
+            rows += int((out[6] > 0).sum())
+        t_ref = time.perf_counter() - t0
+        npts = sum(os.path.getsize(os.path.join(root, "data_3d_raw", seq, "velodyne_points", "data", "%010d.bin" % fr)) // 16 for fr in frames)
+        print(json.dumps({"workload": "process_frames over 20 real frames (%d points, 5 masks each, 21...314 annotated boxes per frame), files -> CSV" % npts,
+                          "process_frames_batched_ms": round(1e3 * t_batch, 2), "process_frames_read_ahead_ms": round(1e3 * t_ahead, 2),
+                          "reference_numpy_statements_ms": round(1e3 * t_ref, 2), "csv_rows": int(len(df)),
+                          "ms_per_frame": {"batched": round(1e3 * t_batch / 20, 3), "read_ahead": round(1e3 * t_ahead / 20, 3),
+                                           "reference_numpy": round(1e3 * t_ref / 20, 3)},
+                          "note": "both sides read the scans and box files and parse the JSON; the package's side also writes the CSV and prints "
+                                  "the analysis; masks are float32 host arrays (10.6 MB per frame cross PCIe in the package's path)"}))
+
+
+if __name__ == "__main__":
+    main()
