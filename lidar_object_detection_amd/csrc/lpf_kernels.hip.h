@@ -3,14 +3,17 @@
 //
 // Kernel map (reference statements: /root/reference/Coding_testes, see include/lpf.h)
 //   lpf_pack16 / lpf_pack_erode / lpf_erode_packed
-//                      masks -> uint32 label image (bit m = mask m); 3x3-cross erosion
+//                      masks -> label image (bit m = mask m); 3x3-cross erosion
 //                      on an LDS-staged tile of packed bits                             (V3:82-97, V3:222)
 //   lpf_k1_project     float4 stream: 4x4 transform, cam2image, clip, label gather,
-//                      per-row wave ballots + per-segment counters                      (V3:565-569, 584, 225)
-//   lpf_tail           one launch for everything after K1:
+//                      per-row wave ballots + three levels of counters                  (V3:565-569, 584, 225)
+//   lpf_tail / lpf_tail_wide   one launch for the two roles after K1:
 //     lists            ballots -> stable valid / per-instance index lists (wave prefix)  (V3:585, 228)
-//     box count        masked points x candidate boxes, slab test -> integer counters    (V3:187-202, 370)
-//     finalize         first-strict-max box scan + per-frame summary, by the frame's last block to arrive (V3:353-379)
+//     box count        masked points x candidate boxes of one 64-box word, slab test -> integer counters   (V3:187-202, 370)
+//   lpf_finalize       first-strict-max box scan + per-frame summary; hands the counters back zeroed       (V3:353-379)
+//   box job            per-frame box preparation (filter_visible_bboxes, transform_bboxes_to_velodyne) and the tables the
+//                      box count reads: slab parameters, float bounds, candidate grid     (V3:556-562, 121-140, 41-52)
+//   lpf_step_t         software-pipelined modes: all of the above as roles of ONE launch per run
 //
 // Arithmetic: everything the reference computes in float64 is float64 here, with the
 // summation order NumPy/OpenBLAS uses (see oracle/lpf_oracle.c); the file is compiled
@@ -1201,9 +1204,8 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     lpf_count_flush(P, fr, wd, tid, LPF_BLOCK, LC.cnt);
 }
 
-// 8 blocks per CU: 58 VGPRs since the frame record lives in scalar registers (lpf_frame_record) and the LDS / memory choices are
-// kept apart (lpf_count_chunk); before that it needed 72, and forced to 64 it spilled six registers per thread to scratch
-// -- HBM traffic too.  16.7 KB LDS.
+// 7 blocks per CU (20 KB LDS): 60 VGPRs since the frame record lives in scalar registers (lpf_frame_record); before that it needed
+// 72, and forced to 64 it spilled six registers per thread to scratch -- HBM traffic too.
 template <bool PRE>
 __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_tail_t(const LpfParams P)
 {
@@ -1277,17 +1279,20 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 }
 
 // ------------------------------------------------------------------------------------
-// STEP (software-pipelined modes): ONE launch carries the streaming kernel of run i, the tail of run i-1 and the
-// summaries of run i-2 -- and, in mode 4, the mask pack of run i+1, whose own streaming kernel the next launch
-// carries.  One scratch set per run in flight, so nothing in a launch depends on anything else in it; the launch
-// boundaries order the runs' phases.  The tail's ~2000 short, latency-bound blocks are dealt out among the K1
-// tiles, eight (one per XCD) after every `kper` tiles, so they trickle through the chip beside the streaming
-// work instead of standing in front of it or behind it; the pack's ~1000 blocks are pure streaming work and come
-// last, where they run while the final tiles drain (dealt among the tiles they cost what they take):
+// STEP (software-pipelined modes): ONE launch carries the streaming kernel of run i, the tail of run i-1, the
+// summaries of run i-2 and the box job of run i (its tables are read by run i's tail, a launch later) -- and, in mode 4,
+// the mask pack of run i+1, whose own streaming kernel the next launch carries.  One scratch set and one box set per run
+// in flight, so nothing in a launch depends on anything else in it; the launch boundaries order the runs' phases.  The
+// tail's ~2000 short, latency-bound blocks are dealt out among the K1 tiles, eight (one per XCD) after every `kper` tiles,
+// so they trickle through the chip beside the streaming work instead of standing in front of it or behind it; the pack's
+// ~1000 blocks are pure streaming work and come last, where they run while the final tiles drain (dealt among the tiles
+// they cost what they take):
 //     blocks [0, nfin8)                               summaries of run i-2 (nfin8 = frames, padded to a multiple of 8)
+//     then nbox8 box-job blocks                       (frames x 64-box words of the run being queued, padded)
 //     then nper periods of (kper K1 tiles, 8 tail blocks)
 //     then the remaining K1 tiles
 //     then the pack blocks
+// In order (no pipelining) the same kernel carries a run's tiles and its box job, nothing else.
 // A K1 block's XCD is blockIdx & 7 throughout (every offset is a multiple of 8), which lpf_k1_tile's tile
 // mapping relies on (speed only).
 // ------------------------------------------------------------------------------------
