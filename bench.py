@@ -559,6 +559,10 @@ def main():
     ap.add_argument("--buffers", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--mode", default=DEFAULT_MODE, choices=sorted(MODES),
                     help="how a step's kernels are queued: " + "; ".join("%s = %s" % (k, v[1]) for k, v in sorted(MODES.items())))
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="keep the GPU busy with untimed steps for this long before the W warm-up steps: after the seconds of host-side "
+                         "set-up the GPU's clocks are down, and they take tens of milliseconds of load to come back (the same kernel "
+                         "averages 95 us in the first 30 ms and 92 us afterwards; 0 = off)")
     ap.add_argument("--static-boxes", action="store_true", help="set the boxes once instead of with every step (the reference's loop "
                                                                 "builds a new box list per frame: V3:556-562)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path without RCCL")
@@ -681,6 +685,15 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item()), queued
 
+        if args.preheat_ms > 0:                             # clocks up (untimed, and not part of the W warm-up steps)
+            t_end = time.perf_counter() + 1e-3 * args.preheat_ms
+            i = 0
+            while time.perf_counter() < t_end:
+                steps_fn[i % nb]()
+                i += 1
+                if i % 64 == 0:
+                    ctx.sync()                              # (bounds what is queued ahead)
+            drain()
         for i in range(warmup):
             steps_fn[i % nb]()
         drain()
@@ -743,6 +756,7 @@ def main():
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
                        "masks": N_MASKS, "boxes": N_BOXES, "boxes_change_every_step": bool(per_step_boxes),
                        "masks_change_every_step": True, "resident_batches_per_gpu": nbuf, "mode": args.mode,
+                       "clock_preheat_ms_before_the_warmup_steps": args.preheat_ms,
                        "host_while_queueing_the_timed_steps": main_run["queued"],
                        "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                        "checked": main_run.get("checked"),

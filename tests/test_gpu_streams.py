@@ -286,9 +286,12 @@ def test_pack_riding_mode_corner_cases(calib):
 
 @pytest.mark.parametrize("mode,kind", [("fused", "f32"), ("fused-pack", "u8"), ("fused-pack", "f32")])
 def test_sample_frames_as_a_software_pipelined_stream(calib, mode, kind):
-    """The 20 KITTI-360 sample frames queued one after the other in a software-pipelined mode, masks lent as the reference has
-    them (float32 0/1, read directly by the tiles of each frame's launch) or as uint8; nothing is synchronised until all are
-    queued.  Every frame must equal the reference's own outputs (tests/golden, generated by the reference's functions)."""
+    """The 20 KITTI-360 sample frames queued one after the other in a software-pipelined mode -- every frame with its own point
+    count, its own masks (lent as the reference has them, float32 0/1, read directly by the tiles of each frame's launch, or as
+    uint8) and its own boxes (host corners, as the reference's loop produces them per frame, V3:556-562).  Nothing is synchronised
+    until all are queued, and lpf_get_stats shows that the context neither waited nor drained while they were: several real
+    frames are in flight together (tiles of one, tail of the one before, summaries of the one before that, in one launch).
+    Every frame must equal the reference's own outputs (tests/golden, generated by the reference's functions)."""
     import torch
     from conftest import golden_frames, load_golden, unpack_masks
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
@@ -296,29 +299,45 @@ def test_sample_frames_as_a_software_pipelined_stream(calib, mode, kind):
     dev = torch.device("cuda", 0)
     tag = "rect5_d50"
     held = []
+    for rec in golden_frames()["frames"]:
+        g = load_golden(rec["frame"])
+        if "u" not in g:
+            continue                                        # frame skipped by the reference (no boxes)
+        masks = unpack_masks(g, "rect5", H, W)
+        M, B, n = masks.shape[0], g["corners_velo"].shape[0], len(g["points"])
+        m = torch.from_numpy(masks if kind == "f32" else masks.astype(np.uint8)).to(dev)
+        pts = torch.from_numpy(np.ascontiguousarray(g["points"], dtype=np.float32)).to(dev)
+        o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                 valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((1, n * max(M, 1)), dtype=torch.int64, device=dev),
+                 count_mb=torch.zeros(max(M * B, 1), dtype=torch.int32, device=dev),
+                 summary=torch.zeros(SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        held.append((g, M, B, o, pts, m, n))
+    assert len(held) >= 15
+    torch.cuda.synchronize(dev)
     with LpfContext(0) as ctx:
         ctx.set_pipelined(mode)
         ctx.set_camera(calib["TrVeloToRect"], calib["K"], W, H, 0.0, 50.0)
-        for rec in golden_frames()["frames"]:
-            g = load_golden(rec["frame"])
-            if "u" not in g:
-                continue                                    # frame skipped by the reference (no boxes)
-            masks = unpack_masks(g, "rect5", H, W)
-            M, B, n = masks.shape[0], g["corners_velo"].shape[0], len(g["points"])
-            m = torch.from_numpy(masks if kind == "f32" else masks.astype(np.uint8)).to(dev)
-            pts = torch.from_numpy(np.ascontiguousarray(g["points"], dtype=np.float32)).to(dev)
-            o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
-                     valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((1, n * max(M, 1)), dtype=torch.int64, device=dev),
-                     count_mb=torch.zeros(max(M * B, 1), dtype=torch.int32, device=dev),
-                     summary=torch.zeros(SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
-            torch.cuda.synchronize(dev)
-            ctx.set_masks(m, lend=True)
-            ctx.set_boxes(g["corners_velo"], oriented=True)
-            ctx.run_device(pts, np.array([0, n], np.int64), inst_cap=n * max(M, 1), **o)
-            held.append((g, M, B, o, pts, m))
+
+        def queue_all():
+            for g, M, B, o, pts, m, n in held:
+                ctx.set_masks(m, lend=True)
+                ctx.set_boxes(g["corners_velo"], oriented=True)
+                ctx.run_device(pts, np.array([0, n], np.int64), inst_cap=n * max(M, 1), **o)
+
+        for _ in range(3):                                  # warm passes: the scratch sets grow to the largest frame (growing waits)
+            queue_all()
         ctx.sync()
-    assert len(held) >= 15
-    for g, M, B, o, pts, m in held:
+        for g, M, B, o, pts, m, n in held:
+            for t in o.values():
+                t.zero_()
+        torch.cuda.synchronize(dev)
+        ctx.stats(reset=True)
+        queue_all()
+        st = ctx.stats()
+        ctx.sync()
+    assert st["host_waits"] == 0 and st["drains"] == 0 and st["blocking_uploads"] == 0, st
+    assert st["step_launches"] == len(held) and st["box_jobs_riding"] == len(held), st
+    for g, M, B, o, pts, m, n in held:
         sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)[0]
         uv = o["uv"].cpu().numpy()
         assert np.array_equal(uv[:, 0], np.clip(g["u"], -2**31, 2**31 - 1).astype(np.int32))
