@@ -1026,11 +1026,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // tail blocks: four consecutive segments of one frame each (an empty frame still gets one, to write its summary);
     // the list blocks, then -- when boxes are to be counted -- as many box-count blocks
     const bool count_boxes = M > 0 && Btot > 0;
-    int nblk = 0, ncblk = 0;                               // list blocks; box-count blocks: one per group of segments and 64-box word
+    // (fused is decided further down; the same condition here)
+    const int csplit = (c->fused && !host_io && pts_on_device && !c->capturing && small) ? 4 : 1;     // count blocks per (group, word): see lpf_tail_block
+    int nblk = 0, ncblk = 0;                               // list blocks; box-count blocks: one per group of segments, 64-box word and part
     for (int f = 0; f < F; ++f) {
         const int nb = c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
         nblk += nb;
-        ncblk += nb * std::max(1, c->h_frames[f].cand_words);
+        ncblk += nb * std::max(1, c->h_frames[f].cand_words) * csplit;
     }
     const size_t rows = (size_t)nseg_cap * (size_t)(seg_pts / 64);
     // a list wave sums one group's segments and the frame's groups, a lane each: frames of more than 64 groups
@@ -1069,12 +1071,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             for (int sg = 0; sg < fr.nseg; ++sg) hs[(size_t)fr.seg_off + sg] = fr;
             if (fr.nseg == 0) {
                 *hb++ = make_int2(fr.seg_off, f << 3);
-                for (int w = 0; w < wpg; ++w) *hc++ = make_int4(fr.seg_off, f, w, 0);
+                for (int w = 0; w < wpg; ++w) for (int r = 0; r < csplit; ++r) *hc++ = make_int4(fr.seg_off, f, w, r << 3);
             }
             for (int sg = 0; sg < fr.nseg; sg += LPF_LISTS_WAVES) {
                 const int nw = std::min(LPF_LISTS_WAVES, fr.nseg - sg);
                 *hb++ = make_int2(fr.seg_off + sg, (f << 3) | nw);
-                for (int w = 0; w < wpg; ++w) *hc++ = make_int4(fr.seg_off + sg, f, w, nw);
+                for (int w = 0; w < wpg; ++w) for (int r = 0; r < csplit; ++r) *hc++ = make_int4(fr.seg_off + sg, f, w, (r << 3) | nw);
             }
         }
         S.tab_frames.clear();                              // (nothing valid if the upload fails half way)
@@ -1123,7 +1125,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.cnt = (unsigned *)S.cnt.p;
-    P.nblk = nblk; P.ncblk = ncblk; P.count_boxes = count_boxes ? 1 : 0;
+    P.nblk = nblk; P.ncblk = ncblk; P.csplit = csplit; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;

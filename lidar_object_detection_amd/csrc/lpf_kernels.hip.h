@@ -64,6 +64,8 @@ struct LpfParams {
     const int2 *blks;            // [nblk] list blocks of the tail: {first segment, frame << 3 | segments (0..4)}
     const int4 *cblks;           // [ncblk] box-count blocks: {first segment, frame, candidate word, segments (0..4)}
     int nblk, ncblk;
+    int csplit;                  // count blocks per (group of segments, word): they share the group's chunks of 64 masked points (1, or 4 in small
+                                 // software-pipelined launches, whose longest chain is a count block on a car)
     const float4 *pts;
     const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
     const double *boxp;          // [Btot][16] exact box parameters
@@ -1054,26 +1056,33 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
     int32_t *bb = base ? (int32_t *)(base + 99 * 8) : nullptr;
     unsigned *__restrict__ cnt = P.cnt + (size_t)M * fr.box_off;
     int32_t *out = P.count_out ? P.count_out + (size_t)M * fr.box_off : nullptr;
-    const bool staged = MB <= LPF_FIN_STAGE;
-    // ONE round trip: the frame's totals (sum of the 8 shards K1's tiles added into) and the inside counts are loaded
-    // together; the counts go to the caller and to LDS, their scratch is handed back zeroed
+    // The inside counts go through LDS in passes of gm whole masks (gm x B <= LPF_FIN_STAGE; nearly always ONE pass with all of
+    // them -- a crowded street scene of 300 boxes x 20 masks takes four); only B > LPF_FIN_STAGE reads them from memory.
+    const bool staged = B <= LPF_FIN_STAGE;
+    const int gm = !staged ? 0 : (B > 0 ? min(M, LPF_FIN_STAGE / B) : M);
+    // ONE round trip: the frame's totals (sum of the 8 shards K1's tiles added into) and the inside counts (first pass) are
+    // loaded together; the counts go to the caller and to LDS, their scratch is handed back zeroed
     const int ngroups = (2 + M + 3) >> 2;
     unsigned a = 0, cv[LPF_FIN_STAGE / LPF_BLOCK];
     if (tid < 4 * ngroups)
         for (int sh = 0; sh < LPF_FRM_SHARDS; ++sh)
             a += reinterpret_cast<const unsigned *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + sh) * LPF_TAB_GROUPS)[tid];
-    if (staged) {
+    auto stage_load = [&](int m0) {                         // counts of masks m0 .. m0 + gm - 1 -> registers (independent loads)
+        const int n = (min(M, m0 + gm) - m0) * B;
 #pragma unroll
-        for (int k = 0; k < LPF_FIN_STAGE / LPF_BLOCK; ++k) cv[k] = (tid + k * LPF_BLOCK < MB) ? cnt[tid + k * LPF_BLOCK] : 0u;
-    }
-    if (tid < LPF_TAB_ROWS) s_tot[tid] = (tid < 2 + M) ? a : 0u;
-    if (staged) {
+        for (int k = 0; k < LPF_FIN_STAGE / LPF_BLOCK; ++k) cv[k] = (tid + k * LPF_BLOCK < n) ? cnt[m0 * B + tid + k * LPF_BLOCK] : 0u;
+    };
+    auto stage_store = [&](int m0) {                        // -> LDS, the caller's counts; the scratch zeroed
+        const int n = (min(M, m0 + gm) - m0) * B;
 #pragma unroll
         for (int k = 0; k < LPF_FIN_STAGE / LPF_BLOCK; ++k) {
             const int i = tid + k * LPF_BLOCK;
-            if (i < MB) { s_c[i] = cv[k]; if (out) out[i] = (int32_t)cv[k]; cnt[i] = 0u; }
+            if (i < n) { s_c[i] = cv[k]; if (out) out[m0 * B + i] = (int32_t)cv[k]; cnt[m0 * B + i] = 0u; }
         }
-    }
+    };
+    if (staged) stage_load(0);
+    if (tid < LPF_TAB_ROWS) s_tot[tid] = (tid < 2 + M) ? a : 0u;
+    if (staged) stage_store(0);
     __syncthreads();
     const unsigned *__restrict__ tot = s_tot;
     {   // ... and the three counter levels are handed back zeroed for the next run (this is their last reader)
@@ -1083,29 +1092,38 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
         for (int i = tid; i < ngroups * ngrp; i += LPF_BLOCK) P.grp_tab[(size_t)(i / ngrp) * P.ngrp_cap + fr.grp_off + (i % ngrp)] = z;
         for (int i = tid; i < LPF_FRM_SHARDS * LPF_TAB_GROUPS; i += LPF_BLOCK) P.frm_tab[(size_t)f * LPF_FRM_SHARDS * LPF_TAB_GROUPS + i] = z;
     }
-    auto cnt_at = [&](int i) {                              // (LDS, or memory for the rare big M x B; kept apart: see lpf_count_chunk)
-        unsigned v = s_c[i & (LPF_FIN_STAGE - 1)];
-        asm volatile("" : "+v"(v));
-        if (!staged) v = cnt[i];
-        return v;
-    };
     // first strict maximum over the boxes, starting from 0: one wave per mask, lanes over boxes
-    for (int m = wave; m < M; m += 4) {
-        unsigned best = 0;
-        int best_idx = 0x7fffffff;
-        for (int b = lane; b < B; b += 64) {
-            const unsigned c = cnt_at(m * B + b);
-            if (c > best) { best = c; best_idx = b; }      // ascending b per lane: keeps the first
-        }
+    auto maxima = [&](int m0, int m1) {
+        for (int m = m0 + wave; m < m1; m += 4) {
+            unsigned best = 0;
+            int best_idx = 0x7fffffff;
+            for (int b = lane; b < B; b += 64) {
+                unsigned c = s_c[((m - m0) * B + b) & (LPF_FIN_STAGE - 1)];       // (LDS; memory for B > LPF_FIN_STAGE, kept apart:
+                asm volatile("" : "+v"(c));                                     //  see lpf_count_chunk)
+                if (!staged) c = cnt[m * B + b];
+                if (c > best) { best = c; best_idx = b; }      // ascending b per lane: keeps the first
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned ob = __shfl_down(best, o);
-            const int oi = __shfl_down(best_idx, o);
-            if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned ob = __shfl_down(best, o);
+                const int oi = __shfl_down(best_idx, o);
+                if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+            }
+            if (lane == 0 && base) {
+                w[67 + m] = (long long)best;
+                bb[m] = best ? best_idx : -1;
+            }
         }
-        if (lane == 0 && base) {
-            w[67 + m] = (long long)best;
-            bb[m] = best ? best_idx : -1;
+    };
+    if (!staged) maxima(0, M);
+    else {
+        maxima(0, min(M, gm));
+        for (int m0 = gm; m0 < M; m0 += gm) {               // (block-uniform; rarely entered)
+            stage_load(m0);
+            __syncthreads();                                // the previous pass's maxima have read s_c
+            stage_store(m0);
+            __syncthreads();
+            maxima(m0, min(M, m0 + gm));
         }
     }
     if (base && tid < 64) {                                // wave 0: counts, offsets, flags
@@ -1144,25 +1162,26 @@ __device__ __forceinline__ void lpf_finalize_frame(const LpfParams &P, const Lpf
 // nothing waits inside the kernel.  lpf_finalize then writes the per-frame summaries.
 // ------------------------------------------------------------------------------------
 // Tail block tables.  List blocks: {first segment, frame << 3 | segments (0..4)} of block i.  Box-count blocks: {first segment,
-// frame, candidate word, segments} -- a group of four segments gets a count block per 64-box word of its frame.
+// frame, candidate word, part << 3 | segments} -- a group of four segments gets a count block per 64-box word of its frame (and,
+// P.csplit > 1, per part: the parts share the group's chunks).
 // A launch of ONE frame needs no table (and so no upload when its size changes from run to run): list block i takes segments
-// 4 i .. 4 i + 3, count block i is (group i / words, word i % words).
+// 4 i .. 4 i + 3, count block i is (group, word, part) = (i / (words csplit), i / csplit % words, i % csplit).
 __device__ __forceinline__ int2 lpf_tail_entry(const LpfParams &P, const int i)
 {
     if (P.F > 1) return P.blks[i];
     const int first = i * LPF_LISTS_WAVES;
     return make_int2(first, max(0, min(LPF_LISTS_WAVES, P.frame0.nseg - first)));
 }
-__device__ __forceinline__ void lpf_count_entry(const LpfParams &P, const int i, int &first, int &f, int &nw, int &wd)
+__device__ __forceinline__ void lpf_count_entry(const LpfParams &P, const int i, int &first, int &f, int &nw, int &wd, int &part)
 {
     if (P.F > 1) {
         const int4 e = P.cblks[i];
-        first = e.x; f = e.y; wd = e.z; nw = e.w;
+        first = e.x; f = e.y; wd = e.z; nw = e.w & 7; part = e.w >> 3;
         return;
     }
-    const int words = max(1, P.frame0.cand_words);
-    const int g = i / words;
-    wd = i - g * words; f = 0; first = g * LPF_LISTS_WAVES;
+    const int words = max(1, P.frame0.cand_words), per = words * P.csplit;
+    const int g = i / per, rem = i - g * per;
+    wd = rem / P.csplit; part = rem - wd * P.csplit; f = 0; first = g * LPF_LISTS_WAVES;
     nw = max(0, min(LPF_LISTS_WAVES, P.frame0.nseg - first));
 }
 
@@ -1174,6 +1193,7 @@ struct LpfTailCountLds {
     float bq[6 * LPF_BC_WORD];                // {lo xyz, hi xyz} float bounds of the word's boxes
     double bp[LPF_BC_WORD * 16];              // their exact parameters
     double tk[21];                            // T (12) and K (9)
+    unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];      // row prefixes of the block's four segments
 };
 
 #define LPF_TAIL_LDS (sizeof(LpfTailCountLds) > sizeof(LpfTailListsLds) ? sizeof(LpfTailCountLds) : sizeof(LpfTailListsLds))
@@ -1194,12 +1214,32 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
         return;
     }
-    int first, f, nw, wd;
-    lpf_count_entry(P, tb, first, f, nw, wd);
+    int first, f, nw, wd, part;
+    lpf_count_entry(P, tb, first, f, nw, wd, part);
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.tk);
+    {                                                       // the block's (up to) four segments: row prefixes -> LDS
+        const int lane = lpf_lane();
+        unsigned im = 0, mbase = 0, L = 0;
+        if (wave < nw) L = lpf_count_rows(P, fr, first + wave, im, mbase);
+        LC.im[wave][lane] = im; LC.mbase[wave][lane] = mbase;
+        if (lane == 0) LC.L[wave] = L;
+    }
     __syncthreads();
-    if (wave < nw) lpf_boxcount_wave(P, fr, first + wave, LC.pt[wave], LC.q[wave], LC.cnt, LC.bq, LC.bp, LC.tk, wd);
+    // The chunks of 64 masked points of the four segments are shared: chunk c goes to wave (c mod 4 csplit) of the group's csplit
+    // blocks.  Consecutive segments of a real scan lie on the same car -- all four heavy or all four empty -- so sharing within one
+    // block gains nothing, sharing over four does (small pipelined launches: frame 100 in a stream 16 -> 12 us per frame).
+    {
+        const int lane = lpf_lane();
+        const unsigned L0 = LC.L[0], L1 = LC.L[1], L2 = LC.L[2], L3 = LC.L[3];
+        const int c0 = (int)((L0 + 63) >> 6), c1 = (int)((L1 + 63) >> 6), c2 = (int)((L2 + 63) >> 6), c3 = (int)((L3 + 63) >> 6);
+        for (int c = part * LPF_LISTS_WAVES + wave; c < c0 + c1 + c2 + c3; c += LPF_LISTS_WAVES * P.csplit) {     // wave-uniform
+            int sg = 0, cc = c;
+            if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
+            lpf_count_chunk(P, fr, first + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
+                            LC.cnt, LC.bq, LC.bp, LC.tk, wd);
+        }
+    }
     __syncthreads();
     lpf_count_flush(P, fr, wd, tid, LPF_BLOCK, LC.cnt);
 }
@@ -1247,8 +1287,8 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
         if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);   // (this form: small launches only)
         return;
     }
-    int first, f, nw, wd;
-    lpf_count_entry(P, tb, first, f, nw, wd);
+    int first, f, nw, wd, part;
+    lpf_count_entry(P, tb, first, f, nw, wd, part);           // (part is always 0 here: the wide form shares over its own 16 waves)
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (wave < LPF_LISTS_WAVES) {                           // the block's (up to) four segments: row prefixes -> LDS
         unsigned im = 0, mbase = 0, L = 0;

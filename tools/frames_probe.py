@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-order and pipelined microseconds per frame for each of the four full-size golden frames alone (their own masks and boxes,
-boxes prepared per frame on the device).  usage: python tools/frames_probe.py [frame number: only that frame, e.g. under rocprofv3 --kernel-trace --stats]"""
+boxes prepared per frame on the device).  usage: python tools/frames_probe.py [frame number: only that frame, e.g. under rocprofv3 --kernel-trace --stats] [static|noboxes|nolists]"""
 import os
 import sys
 import time
@@ -18,6 +18,7 @@ cal = np.load(os.path.join(gdir, "calib_cam0.npz"))
 T, K, W, H = np.asarray(cal["TrVeloToRect"]), np.asarray(cal["K"])[:3, :3], int(cal["width"]), int(cal["height"])
 Tcv = np.linalg.inv(np.asarray(cal["TrVeloToCam"]))
 only = sys.argv[1] if len(sys.argv) > 1 else ""
+variant = sys.argv[2] if len(sys.argv) > 2 else ""      # "static": boxes set once; "noboxes": no boxes at all; "nolists": no index lists
 for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002098_full.npz", "frame_0000002449_full.npz"):
     if only and only not in name:
         continue
@@ -35,8 +36,14 @@ for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002
         with LpfContext(0) as ctx:
             ctx.set_pipelined(mode)
             ctx.set_camera(T, K, W, H, 0.0, 50.0)
-            fn = ctx.make_device_step(pts, np.array([0, n], np.int64), masks_u8=masks, lend=True, boxes_cam0=cam0, box_off=np.array([0, B], np.int32),
-                                      T_cam_to_velo=Tcv, inst_cap=n, **o)
+            oo = dict(o)
+            if variant == "nolists":
+                oo["valid_idx"] = None; oo["inst_idx"] = None
+            if variant == "static":
+                ctx.set_boxes_cam0_device(cam0, np.array([0, B], np.int32), Tcv, lend=True)
+            fn = ctx.make_device_step(pts, np.array([0, n], np.int64), masks_u8=masks, lend=True,
+                                      boxes_cam0=cam0 if variant not in ("static", "noboxes") else None, box_off=np.array([0, B], np.int32),
+                                      T_cam_to_velo=Tcv, inst_cap=n, **oo)
             for _ in range(30):
                 fn()
             ctx.sync()
@@ -45,4 +52,4 @@ for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002
                 fn()
             ctx.sync()
             res.append(1e3 * (time.perf_counter() - t0))
-    print("%s: N=%d boxes %d (kept %d): in order %.1f us, pipelined stream %.1f us per frame" % (name[:16], n, B, len(g["visible_pos"]), res[0], res[1]), flush=True)
+    print("%s %s: N=%d boxes %d (kept %d): in order %.1f us, pipelined stream %.1f us per frame" % (name[:16], variant, n, B, len(g["visible_pos"]), res[0], res[1]), flush=True)
