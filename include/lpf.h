@@ -143,6 +143,10 @@ int  lpf_set_pipelined(lpf_ctx *ctx, int on);
  * prefixes taken from the scan kernel (what frames of more than 64 x 64 segments get by themselves), 4 = small with the
  * narrow tail. */
 int  lpf_set_geometry(lpf_ctx *ctx, int mode);
+/* Role clock of the step launches of the software-pipelined modes: out[6][5] = per role (0 summaries, 1 box job, 2 lists, 3 box
+ * counts, 4 mask pack, 5 project+label tiles) {first block start, last block end, sum of block durations, blocks, longest block}
+ * in ticks of the 100 MHz wall clock, accumulated since the last reset.  The first call switches it on.  Synchronises. */
+int  lpf_lab_role_clock(lpf_ctx *ctx, unsigned long long *out, int reset);
 #endif
 
 /* ---- per-sequence state --------------------------------------------------------

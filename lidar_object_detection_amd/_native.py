@@ -85,6 +85,7 @@ def load(path=None):
     lib.lpf_set_pipelined.argtypes = [_P, ctypes.c_int]
     if hasattr(lib, "lpf_set_geometry"):                     # lab builds only (-DLPF_LAB)
         lib.lpf_set_geometry.argtypes = [_P, ctypes.c_int]
+        lib.lpf_lab_role_clock.argtypes = [_P, _P, ctypes.c_int]
     lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -318,6 +319,23 @@ class LpfContext:
         if not hasattr(self._lib, "lpf_set_geometry"):
             raise LpfError(-3, "lpf_set_geometry exists in lab builds only (python -m lidar_object_detection_amd._build lab; LPF_LIBRARY=...)")
         self._check(self._lib.lpf_set_geometry(self._h, {"auto": 0, "small": 1, "large": 2, "large-scan": 3, "small-narrow": 4}[mode]))
+
+    ROLES = ("summaries", "box job", "lists", "box counts", "mask pack", "project+label tiles")
+
+    def role_clock(self, reset=True):
+        """LAB BUILDS ONLY.  Per role of the step launches of the software-pipelined modes since the last reset: {role: dict(span_us =
+        first block start .. last block end, blocks, mean_us, longest_us)}; the first call switches the clock on.  Synchronises."""
+        if not hasattr(self._lib, "lpf_lab_role_clock"):
+            raise LpfError(-3, "lpf_lab_role_clock exists in lab builds only (python -m lidar_object_detection_amd._build lab; LPF_LIBRARY=...)")
+        a = np.zeros((6, 5), np.uint64)
+        self._check(self._lib.lpf_lab_role_clock(self._h, a.ctypes.data, 1 if reset else 0))
+        out = {}
+        for r, name in enumerate(self.ROLES):
+            n = int(a[r, 3])
+            if n:
+                out[name] = dict(span_us=(int(a[r, 1]) - int(a[r, 0])) / 100.0, blocks=n, mean_us=int(a[r, 2]) / 100.0 / n, longest_us=int(a[r, 4]) / 100.0,
+                                 first_start_tick=int(a[r, 0]), last_end_tick=int(a[r, 1]))
+        return out
 
     def allreduce_metrics(self, vec, rccl_comm, op="sum"):
         """In-place all-reduce of an int64 NumPy vector over an RCCL communicator (an ncclComm_t as an integer /

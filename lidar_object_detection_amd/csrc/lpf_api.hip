@@ -84,7 +84,7 @@ struct lpf_ctx {
         int max_words = 1;                        // 64-bit words per cell of the frame with the most boxes
         DevBuf boxp;                              // [Btot][16] double
         DevBuf boxq;                              // [Btot][8] float conservative AABB
-        DevBuf cand;                              // candidate-box grid
+        DevBuf cand;                              // ground grids: LPF_GRID_WORDS words per 64 boxes of a frame
         DevBuf corners;                           // [Btot][8][3] velodyne-frame corners the tables were built from (kept: a camera change rebuilds them)
         DevBuf enabled;                           // [Btot] bytes: 0 = dropped by filter_visible_bboxes (lpf_set_boxes_cam0)
         DevBuf aux;                               // lpf_set_boxes_cam0 for host callers: projected 2D boxes + front counts
@@ -136,6 +136,7 @@ struct lpf_ctx {
     // lpf_get_stats: [0] host waits, [1] drains (owed work launched outside a run), [2] uploads through the pinned ring, [3] step
     // launches, [4] box jobs launched as a kernel of their own, [5] box jobs that rode in a step launch, [6] blocking uploads
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    DevBuf lab_clk;                   // LPF_LAB builds (lpf_lab_role_clock): 6 roles x 5 counters, or empty
     int geometry = 0;                 // LPF_LAB builds (lpf_set_geometry): 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes, 4 small + narrow tail
 
     // Pinned host ring for small uploads (tables, host corners) that must not block: the source of an asynchronous copy has to
@@ -198,16 +199,13 @@ void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
     else hipLaunchKernelGGL((lpf_tail_t<false>), dim3((unsigned)ntail), dim3(LPF_BLOCK), 0, st, P);
 }
 
-#define LPF_CELL_SHIFT 5
-
 // camera-dependent fields of a box job: filled when the job is launched, so a job that waits for its run always sees the
 // camera of that run
 void box_job_camera(const lpf_ctx *c, LpfBoxJob &J)
 {
     memcpy(J.T, c->T, sizeof J.T);
     memcpy(J.K, c->K, sizeof J.K);
-    J.W = c->W; J.H = c->H; J.cell_shift = LPF_CELL_SHIFT;
-    J.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT; J.cell_h = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
+    J.W = c->W; J.H = c->H;
 }
 
 // blocks of a set's box job: frames x 64-box chunks of the frame with the most boxes
@@ -241,6 +239,9 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     LpfPackJob J;
     memset(&J, 0, sizeof J);
     Y.nfin = R.valid ? R.P.F : 0;
+#ifdef LPF_LAB
+    Y.clk = (unsigned long long *)c->lab_clk.p;
+#endif
     Y.nfin8 = (Y.nfin + 7) & ~7;
     const bool boxes = XB && XB->job_valid && XB->F > 0 && XB->box_off[XB->F] > 0;
     if (XB) XB->job_valid = false;
@@ -444,7 +445,7 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
     if (F > 0 && box_off[0] != 0) return fail(c, LPF_ERR_ARG, "%s: box_off[0] must be 0", who);
     for (int f = 0; f < F; ++f)
         if (box_off[f + 1] < box_off[f]) return fail(c, LPF_ERR_ARG, "%s: box_off not ascending at %d", who, f);
-    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "%s: lpf_set_camera must be called first (the candidate grid is per image cell)", who);
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "%s: lpf_set_camera must be called first (cam-0 boxes are filtered with its K, W, H)", who);
     int rc;
     lpf_ctx::BoxSet *B = &c->bx[c->box_cur];
     if (c->fused && !c->capturing) {
@@ -459,8 +460,6 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
         if (B->last_ref >= 0 && B->last_ref + depth >= c->run_seq && (rc = flush_pending(c))) return rc;
     }
     B->used = false; B->last_ref = -1; B->job_valid = false; B->F = 0;
-    const int cw = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT, ch = (c->H + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
-    const size_t ncell = (size_t)cw * ch;
     B->h_bframes.resize((size_t)F);
     B->cand_off.assign((size_t)F, 0);
     B->max_words = 1;
@@ -469,7 +468,7 @@ int box_layout(lpf_ctx *c, const int32_t *box_off, int F, int oriented, const ch
         const int nb = box_off[f + 1] - box_off[f];
         B->h_bframes[f].box_off = box_off[f]; B->h_bframes[f].B = nb; B->h_bframes[f].cand_off = (long long)total;
         B->cand_off[f] = (long long)total;
-        total += ncell * (size_t)((nb + 63) / 64);
+        total += (size_t)LPF_GRID_WORDS * (size_t)((nb + 63) / 64);      // a ground grid per 64 boxes
         if ((nb + 63) / 64 > B->max_words) B->max_words = (nb + 63) / 64;
     }
     const int Btot = F ? box_off[F] : 0;
@@ -762,7 +761,7 @@ void lpf_destroy(lpf_ctx *c)
         DevBuf *bb[] = {&B.boxp, &B.boxq, &B.cand, &B.corners, &B.enabled, &B.aux, &B.bframes, &B.stage};
         for (DevBuf *b : bb) release(*b);
     }
-    DevBuf *all[] = {&c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -849,6 +848,26 @@ int lpf_set_geometry(lpf_ctx *c, int mode)
     ++c->generation;
     return LPF_OK;
 }
+
+// Role clock of the step launches (software-pipelined modes): out[6][5] = per role {first block start, last block end, sum of the
+// block durations, blocks, longest block} in ticks of the 100 MHz wall clock, accumulated since the last reset.  The first call
+// switches the clock on (the step kernel of a lab build then ends every block with a barrier and four atomics).  Synchronises.
+int lpf_lab_role_clock(lpf_ctx *c, unsigned long long *out, int reset)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    unsigned long long init[30];
+    for (int r = 0; r < 6; ++r) { init[5 * r] = ~0ull; init[5 * r + 1] = init[5 * r + 2] = init[5 * r + 3] = init[5 * r + 4] = 0ull; }
+    if (!c->lab_clk.p) {
+        if ((rc = reserve(c, c->lab_clk, sizeof init))) return rc;
+        if (hipMemcpy(c->lab_clk.p, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_lab_role_clock: hipMemcpy");
+    }
+    if (out && hipMemcpy(out, c->lab_clk.p, sizeof init, hipMemcpyDeviceToHost) != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_lab_role_clock: hipMemcpy");
+    if (reset && hipMemcpy(c->lab_clk.p, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) return fail(c, LPF_ERR_HIP, "lpf_lab_role_clock: hipMemcpy");
+    return LPF_OK;
+}
 #endif
 
 int lpf_set_pipelined(lpf_ctx *c, int on)
@@ -877,13 +896,13 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     if (!c) return LPF_ERR_ARG;
     if (!T || !K || W <= 0 || H <= 0 || (long long)W * H > (1ll << 30))
         return fail(c, LPF_ERR_ARG, "set_camera: T=%p K=%p W=%d H=%d", (const void *)T, (const void *)K, W, H);
-    // pipelined modes: a run still owed projects / counts boxes with the OLD camera (its candidate grid, its box job)
+    // pipelined modes: a run still owed projects / counts boxes with the OLD camera (its box job)
     if (!c->capturing && (anything_owed(c) || c->bx[c->box_cur].job_valid)) {
         if (use_device(c)) return LPF_ERR_HIP;
         int rc_ = sync_all(c);
         if (rc_) return rc_;
     }
-    if (W != c->W || H != c->H) {            // label images and the candidate grid are per W x H: set masks / boxes again
+    if (W != c->W || H != c->H) {            // label images (and the visibility filter of cam-0 boxes) are per W x H: set masks / boxes again
         c->mask_F = 0; c->mask_M = 0; c->lazy.valid = false; c->ride.valid = false;
         for (auto &B : c->bx) { B.F = 0; B.box_off.clear(); B.job_valid = false; }
     }
@@ -891,7 +910,7 @@ int lpf_set_camera(lpf_ctx *c, const double T[16], const double K[9], int W, int
     memcpy(c->K, K, sizeof c->K);
     c->W = W; c->H = H; c->dmin = dmin; c->dmax = dmax;
     c->have_camera = true;
-    c->cand_dirty = true;                    // the candidate grid depends on T, K, W, H
+    c->cand_dirty = true;                    // a cam-0 box job filters with K, W, H: the current set's tables are rebuilt
     ++c->generation;                         // T, K, W, H are kernel arguments of a captured graph
     return LPF_OK;
 }
@@ -1120,7 +1139,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.label_img = (M > 0) ? (direct ? c->lazy.p : direct_fused ? c->ride.masks : SM.label_cur) : nullptr;
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)BX.boxp.p; P.boxq = (const float *)BX.boxq.p;
-    P.cand = (const unsigned long long *)BX.cand.p; P.cell_shift = LPF_CELL_SHIFT; P.cell_w = (c->W + (1 << LPF_CELL_SHIFT) - 1) >> LPF_CELL_SHIFT;
+    P.cand = (const unsigned long long *)BX.cand.p;
     P.vbal = (unsigned long long *)S.vbal.p; P.mbal = (unsigned long long *)S.mbal.p;
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;

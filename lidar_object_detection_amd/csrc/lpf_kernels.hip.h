@@ -12,7 +12,7 @@
 //     box count        masked points x candidate boxes of one 64-box word, slab test -> integer counters   (V3:187-202, 370)
 //   lpf_finalize       first-strict-max box scan + per-frame summary; hands the counters back zeroed       (V3:353-379)
 //   box job            per-frame box preparation (filter_visible_bboxes, transform_bboxes_to_velodyne) and the tables the
-//                      box count reads: slab parameters, float bounds, candidate grid     (V3:556-562, 121-140, 41-52)
+//                      box count reads: slab parameters, float bounds, ground grids       (V3:556-562, 121-140, 41-52)
 //   lpf_step_t         software-pipelined modes: all of the above as roles of ONE launch per run
 //
 // Arithmetic: everything the reference computes in float64 is float64 here, with the
@@ -40,8 +40,8 @@ struct LpfFrame {                // one per frame, device + host copy
     int box_off;                 // first box of the frame
     int B;                       // boxes of the frame
     int pad;                     // frame index (set by the host)
-    long long cand_off;          // first word of the frame's candidate-box grid
-    int cand_words;              // 64-bit words per grid cell = ceil(B / 64)
+    long long cand_off;          // first word of the frame's candidate-box grids
+    int cand_words;              // grids of the frame: one per 64 boxes = ceil(B / 64)
     int grp_off;                 // first group (of LPF_GROUP_SEGS segments) of the frame
     int pad3, pad4;
 };
@@ -70,8 +70,7 @@ struct LpfParams {
     const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
     const double *boxp;          // [Btot][16] exact box parameters
     const float *boxq;           // [Btot][8]  conservative float AABB {lo xyz, hi xyz}
-    const unsigned long long *cand;   // per frame [cells][cand_words]: boxes whose accepted region can project into the cell
-    int cell_w, cell_shift;      // cells per image row, log2(cell size in pixels)
+    const unsigned long long *cand;   // per (frame, 64-box word) a ground grid (LPF_GRID_WORDS words): see lpf_box_frame_block
     // outputs (nullable)
     int2 *uv;
     uint32_t *label_bits;
@@ -889,18 +888,34 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
 // BOX COUNT: count_mb[m][b] = number of points of mask m inside box b (V3:344-376: np.sum(oriented_point_in_bbox(...))).
 // One WAVE = one segment, like the lists -- and independent of them: the wave compacts its segment's masked points
 // itself (entry e -> ballot row by a binary search over the row prefixes -> K1 wave slot -> hand-off entry), so the
-// two run side by side in one launch.  The frame's candidate grid (built with the boxes) lists, per 32x32-pixel cell,
-// the boxes whose accepted region can project there; a point only meets those.  Candidates pass a conservative float
+// two run side by side in one launch.  The frame's ground grids (built with the boxes, one per 64 of them) list, per cell of the
+// (x, y) plane, the boxes whose bounds reach into it; a point only meets those of its cell.  Candidates pass a conservative float
 // AABB of the region first, the survivors are queued per wave and take the reference's f64 test a whole wave at a
 // time.  Hits are counted in the block's LDS counters and flushed once per block.
 // ------------------------------------------------------------------------------------
-#define LPF_BC_WORD 64            // boxes of a box-count block: ONE 64-box word of its frame's candidate grid.  A frame with more boxes gets a
+#define LPF_BC_WORD 64            // boxes of a box-count block: ONE 64-box word of its frame (one ground grid).  A frame with more boxes gets a
                                   // block per word (and 4 segments): each keeps its 64 boxes' float bounds (24 bytes each), exact parameters
                                   // (128 bytes each) and inside counters (16 bits each, M x 64) in LDS -- whatever the frame's box count, the
                                   // candidate loop and the exact tests never read box data from memory.  (With the frame's first 64 / 32 boxes
                                   // staged and the rest read from memory, a chunk of 64 masked points of a 314-box frame took ~30 us.)
 
 // row prefixes of a segment's masked ballots: lane r -> entries in rows 0..r (im) and before row r (mbase); returns the total
+// The candidate structure: per (frame, word of 64 boxes) a GROUND grid -- LPF_GRID x LPF_GRID cells over the (x, y) extent of the
+// word's boxes in the velodyne frame, a 64-bit box set per cell, and behind the cells the grid's domain {x0, y0, 1/cell_x, 1/cell_y}
+// as four floats.  Seen from above, annotated objects hardly overlap (seen from the camera, everything along a ray does: a street
+// of 300 boxes put 50 candidates on a point).  A box is entered in the cells [cell(lo), cell(hi)] of its float bounds, a point
+// looks into cell(p): the SAME monotone function on both sides, so lo <= p <= hi (the float bounds test every candidate takes
+// first, itself a superset of the exact test) implies the box is in the point's cell.
+#define LPF_GRID 32              // (cells of a metre at least: see the domain in lpf_box_frame_block)
+#define LPF_GRID_CELLS (LPF_GRID * LPF_GRID)
+#define LPF_GRID_WORDS (LPF_GRID_CELLS + 2)
+__device__ __forceinline__ int lpf_ground_cell(const float v, const float v0, const float inv)
+{
+    float t = (v - v0) * inv;                               // monotone in v (inv >= 0); NaN (inf * 0) -> cell 0 below
+    t = fminf(fmaxf(t, 0.f), (float)(LPF_GRID - 1));
+    return (int)t;
+}
+
 __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const LpfFrame &fr, const int sid, unsigned &im, unsigned &mbase)
 {
     const int lane = lpf_lane();
@@ -925,7 +940,7 @@ __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const Lpf
 // boxes 64 wd .. 64 wd + 63, whose bounds / exact parameters / counters the block holds in LDS under their index in the word
 __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFrame &fr, const int sid, const unsigned im, const unsigned mbase,
                                                 const unsigned L, const unsigned e0, float4 *s_pt, unsigned *qq, unsigned *s_cnt,
-                                                const float *s_bq, const double *s_bp, const double *s_tk, const int wd)
+                                                const float *s_bq, const double *s_bp, const float *s_dom, const int wd)
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -969,13 +984,8 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
     s_pt[lane] = p;                                         // .w carries the label bits (0 for idle lanes)
     __builtin_amdgcn_wave_barrier();
     int qn = 0;                                             // wave-uniform queue length
-    int cell = 0;
-    if (act) {                                              // same arithmetic as K1 => the same pixel; masked => valid => in range
-        double uf, vf, d;
-        lpf_project_point_mem(s_tk, p.x, p.y, p.z, uf, vf, d);
-        cell = ((int)rint(vf) >> P.cell_shift) * P.cell_w + ((int)rint(uf) >> P.cell_shift);
-    }
-    unsigned long long mset = act ? P.cand[fr.cand_off + (size_t)cell * fr.cand_words + wd] : 0ull;
+    const int cell = lpf_ground_cell(p.y, s_dom[1], s_dom[3]) * LPF_GRID + lpf_ground_cell(p.x, s_dom[0], s_dom[2]);
+    unsigned long long mset = act ? P.cand[fr.cand_off + (size_t)wd * LPF_GRID_WORDS + cell] : 0ull;
     while (__any(mset != 0ull)) {
         const bool has = mset != 0ull;
         const int j = has ? __ffsll((long long)mset) - 1 : 0;
@@ -1006,17 +1016,17 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
 
 // a wave takes a whole segment (big sparse launches: a chunk or so per segment)
 __device__ __forceinline__ void lpf_boxcount_wave(const LpfParams &P, const LpfFrame &fr, const int sid, float4 *s_pt, unsigned *qq,
-                                                  unsigned *s_cnt, const float *s_bq, const double *s_bp, const double *s_tk, const int wd)
+                                                  unsigned *s_cnt, const float *s_bq, const double *s_bp, const float *s_dom, const int wd)
 {
     unsigned im, mbase;
     const unsigned L = lpf_count_rows(P, fr, sid, im, mbase);
-    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, s_bq, s_bp, s_tk, wd);
+    for (unsigned e0 = 0; e0 < L; e0 += 64) lpf_count_chunk(P, fr, sid, im, mbase, L, e0, s_pt, qq, s_cnt, s_bq, s_bp, s_dom, wd);
 }
 
-// Box data of word wd of the frame (boxes 64 wd ..) and the camera constants -> LDS, the block's counters zeroed; and, after the
+// Box data of word wd of the frame (boxes 64 wd ..) and the domain of its ground grid -> LDS, the block's counters zeroed; and, after the
 // counting, the counters flushed into the frame's [M][B] counts.  nthr threads take part.
 __device__ __forceinline__ void lpf_count_stage(const LpfParams &P, const LpfFrame &fr, const int wd, const int tid, const int nthr,
-                                                unsigned *s_cnt, float *s_bq, double *s_bp, double *s_tk)
+                                                unsigned *s_cnt, float *s_bq, double *s_bp, float *s_dom)
 {
     const int b0 = wd * LPF_BC_WORD, nb = min(fr.B - b0, LPF_BC_WORD);
     const float *__restrict__ bqf = P.boxq + ((size_t)fr.box_off + b0) * 8;          // 8 floats per box: {lo xyz, -, hi xyz, -}
@@ -1024,8 +1034,7 @@ __device__ __forceinline__ void lpf_count_stage(const LpfParams &P, const LpfFra
     for (int i = tid; i < (P.M * LPF_BC_WORD + 1) >> 1; i += nthr) s_cnt[i] = 0u;
     for (int i = tid; i < nb * 6; i += nthr) { const int bx = i / 6, j = i - 6 * bx; s_bq[i] = bqf[8 * bx + (j < 3 ? j : j + 1)]; }
     for (int i = tid; i < nb * 16; i += nthr) s_bp[i] = boxp[i];
-    if (tid < 12) s_tk[tid] = P.T[tid];
-    else if (tid < 21) s_tk[tid] = P.K[tid - 12];
+    if (tid < 4) s_dom[tid] = reinterpret_cast<const float *>(P.cand + fr.cand_off + (size_t)wd * LPF_GRID_WORDS + LPF_GRID_CELLS)[tid];
 }
 __device__ __forceinline__ void lpf_count_flush(const LpfParams &P, const LpfFrame &fr, const int wd, const int tid, const int nthr, const unsigned *s_cnt)
 {
@@ -1192,7 +1201,7 @@ struct LpfTailCountLds {
     unsigned cnt[LPF_MAX_MASKS_DEV * LPF_BC_WORD / 2];     // the block's inside counts [M][64], 16 bits each
     float bq[6 * LPF_BC_WORD];                // {lo xyz, hi xyz} float bounds of the word's boxes
     double bp[LPF_BC_WORD * 16];              // their exact parameters
-    double tk[21];                            // T (12) and K (9)
+    float dom[4];                             // the word's ground grid: {x0, y0, 1 / cell_x, 1 / cell_y}
     unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];      // row prefixes of the block's four segments
 };
 
@@ -1217,7 +1226,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     int first, f, nw, wd, part;
     lpf_count_entry(P, tb, first, f, nw, wd, part);
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
-    lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.tk);
+    lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.dom);
     {                                                       // the block's (up to) four segments: row prefixes -> LDS
         const int lane = lpf_lane();
         unsigned im = 0, mbase = 0, L = 0;
@@ -1237,7 +1246,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
             int sg = 0, cc = c;
             if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
             lpf_count_chunk(P, fr, first + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
-                            LC.cnt, LC.bq, LC.bp, LC.tk, wd);
+                            LC.cnt, LC.bq, LC.bp, LC.dom, wd);
         }
     }
     __syncthreads();
@@ -1269,7 +1278,7 @@ struct LpfTailWideLds {
     unsigned cnt[LPF_MAX_MASKS_DEV * LPF_BC_WORD / 2];
     float bq[6 * LPF_BC_WORD];
     double bp[LPF_BC_WORD * 16];
-    double tk[21];
+    float dom[4];
     unsigned im[LPF_LISTS_WAVES][64], mbase[LPF_LISTS_WAVES][64], L[LPF_LISTS_WAVES];
 };
 
@@ -1296,7 +1305,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
         LC.im[wave][lane] = im; LC.mbase[wave][lane] = mbase;
         if (lane == 0) LC.L[wave] = L;
     }
-    lpf_count_stage(P, fr, wd, tid, 64 * LPF_WIDE_WAVES, LC.cnt, LC.bq, LC.bp, LC.tk);
+    lpf_count_stage(P, fr, wd, tid, 64 * LPF_WIDE_WAVES, LC.cnt, LC.bq, LC.bp, LC.dom);
     __syncthreads();
     const unsigned L0 = LC.L[0], L1 = LC.L[1], L2 = LC.L[2], L3 = LC.L[3];
     const int c0 = (int)((L0 + 63) >> 6), c1 = (int)((L1 + 63) >> 6), c2 = (int)((L2 + 63) >> 6), c3 = (int)((L3 + 63) >> 6);
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
         int sg = 0, cc = c;
         if (cc >= c0) { cc -= c0; sg = 1; if (cc >= c1) { cc -= c1; sg = 2; if (cc >= c2) { cc -= c2; sg = 3; } } }
         lpf_count_chunk(P, fr, first + sg, LC.im[sg][lane], LC.mbase[sg][lane], LC.L[sg], (unsigned)cc * 64u, LC.pt[wave], LC.q[wave],
-                        LC.cnt, LC.bq, LC.bp, LC.tk, wd);
+                        LC.cnt, LC.bq, LC.bp, LC.dom, wd);
     }
     __syncthreads();
     lpf_count_flush(P, fr, wd, tid, 64 * LPF_WIDE_WAVES, LC.cnt);
@@ -1344,7 +1353,28 @@ struct LpfStepLayout {
     int nk1;                     // K1 tiles of run i
     int npack;                   // mask-pack blocks (mode 4: of the run whose K1 tiles the NEXT launch carries), after all K1 tiles
     int rest;                    // K1 block slots after the periods
+#ifdef LPF_LAB
+    unsigned long long *clk;     // role clock (lpf_lab_role_clock), or null: per role {first start, last end, sum, blocks, longest block}
+#endif
 };
+// Lab builds: how long the blocks of each role of a step launch run, in ticks of the 100 MHz wall clock (tools/role_clock.py).
+// Roles: 0 summaries, 1 box job, 2 lists, 3 box counts, 4 mask pack, 5 project+label tiles.
+#ifdef LPF_LAB
+#define LPF_ROLE_BEGIN const unsigned long long t0_ = wall_clock64();
+#define LPF_ROLE_END(role)                                                                                              \
+    if (Y.clk) {                                                                                                        \
+        __syncthreads();                                                                                                \
+        if (threadIdx.x == 0) {                                                                                         \
+            const unsigned long long t1_ = wall_clock64();                                                              \
+            unsigned long long *k_ = Y.clk + 5 * (role);                                                                \
+            atomicMin(k_, t0_); atomicMax(k_ + 1, t1_); atomicAdd(k_ + 2, t1_ - t0_); atomicAdd(k_ + 3, 1ull);          \
+            atomicMax(k_ + 4, t1_ - t0_);                                                                               \
+        }                                                                                                               \
+    }
+#else
+#define LPF_ROLE_BEGIN
+#define LPF_ROLE_END(role)
+#endif
 struct LpfBoxFrame {             // per frame, host-built from the box counts
     int box_off, B;
     long long cand_off;          // first word of the frame's grid
@@ -1355,7 +1385,7 @@ struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_
     int cam0, filter_visible, oriented, F;
     double Tcv[12];              // rows 0..2 of inv(TrVeloToCam) (cam0 = 1)
     double T[12], K[9];          // TrVeloToRect rows 0..2, camera.K[:3,:3]
-    int W, H, cell_shift, cell_w, cell_h, chunks;    // chunks: blocks per frame = 64-bit words of the frame with the most boxes
+    int W, H, chunks;            // chunks: blocks per frame = 64-bit words of the frame with the most boxes
     const LpfBoxFrame *bframes;  // [F] (F > 1)
     LpfBoxFrame frame0;          // ... by value for one frame
     double *boxp; float *boxq; unsigned long long *cand;
@@ -1365,6 +1395,9 @@ struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_
 };
 struct LpfBoxJobLds {
     double c[32][8][3];           // velodyne-frame corners of the pass's 32 boxes, then its intermediate results (8 slots per box)
+    unsigned long long grid[LPF_GRID_CELLS];      // the word's ground grid while it is built
+    float bnd[64][4];             // {lo x, lo y, hi x, hi y} of the float bounds of the word's 64 boxes (empty: lo > hi)
+    float dom[4];                 // the grid's domain
 };
 
 __device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int blk, char *s_raw);
@@ -1385,17 +1418,19 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_STEP_LDS];
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
     int b = (int)blockIdx.x;
+    LPF_ROLE_BEGIN
     if (b < Y.nfin8) {                                      // ---- summaries of run i-2
         if (b < Y.nfin) {
             const LpfFrame fr = lpf_frame_record(R.frame0, R.frames, R.F > 1, b);
             lpf_finalize_frame(R, fr, b, s_cnt, reinterpret_cast<unsigned *>(s_raw));      // (16.7 KB of role LDS: room for the 4 KB stage)
+            LPF_ROLE_END(0)
         }
         return;
     }
     b -= Y.nfin8;
     if (b < Y.nbox8) {                                      // ---- box tables of the run that follows (a block per frame): they are read
         if constexpr (BOXES) {                              //      by its tail, one (mode 2) or two (mode 4) launches from here
-            if (b < Y.nbox) lpf_box_frame_block(X, b, s_raw);
+            if (b < Y.nbox) { lpf_box_frame_block(X, b, s_raw); LPF_ROLE_END(1) }
         }
         return;
     }
@@ -1406,7 +1441,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         const int per = b / plen, pos = b - per * plen;
         if (pos >= Y.kper) {                                // ---- tail of run i-1, then the mask pack (mode 4)
             const int tb = per * 8 + (pos - Y.kper);
-            if (tb < Y.ntail) lpf_tail_block<PRE, 2>(Q, tb, s_raw);
+            if (tb < Y.ntail) { lpf_tail_block<PRE, 2>(Q, tb, s_raw); LPF_ROLE_END(tb < Q.nblk ? 2 : 3) }
             return;
         }
         vblk = ((per * (Y.kper >> 3) + (pos >> 3)) << 3) | (pos & 7);
@@ -1414,7 +1449,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         const int r = b - periodic;
         if (r >= Y.rest) {                                  // ---- the mask pack (mode 4): behind the tiles, it fills their ramp-down
             if constexpr (!LpfIsDirect<LT>::value) {        // (tiles that read the masks directly never share a launch with a pack)
-                if (r - Y.rest < Y.npack) lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest);
+                if (r - Y.rest < Y.npack) { lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest); LPF_ROLE_END(4) }
             }
             return;
         }
@@ -1424,6 +1459,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
     const int x = vblk & 7, q = Y.nk1 >> 3, rem = Y.nk1 & 7;
     if ((vblk >> 3) >= q + (x < rem ? 1 : 0)) return;
     lpf_k1_tile<ROWS, FL, LT>(P, vblk, s_cnt);
+    LPF_ROLE_END(5)
 }
 
 // ------------------------------------------------------------------------------------
@@ -1540,15 +1576,12 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_prep_kernel(const LpfBoxPre
 //            V3:187-197) or { lo, hi } for the axis-aligned test (V3:158-162): the same operations in the same order as
 //            the reference's NumPy statements, so the counting kernels decide exactly as it does;
 //   boxq[b]  a conservative float AABB of the accepted region;
-//   cand     per 32x32-pixel cell the bit set of the boxes whose accepted region can project into it (the region is convex
-//            and the camera a pinhole, so the projections of its 8 vertices bound its image; a region reaching behind the
-//            camera, or an unbounded / degenerate one, is a candidate everywhere).
+//   cand     per 64 boxes a ground grid: per cell the bit set of the boxes whose float bounds reach into it (above: lpf_ground_cell).
 // boxq and cand only skip hopeless (point, box) pairs: every candidate still takes the exact test.
-// Eight lanes share a box (lane = corner, then lane = vertex of the accepted region), 32 boxes per pass of the block.  The
-// block first stores zeros over its frame's grid, then every box ORs its bit into the cells of its rectangle (integer atomics
-// in the one L2 the block's CU writes through): no memset launch in front, nothing to clean afterwards, work proportional to
-// the cells the boxes cover.
-// A box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no candidate cell.
+// Eight lanes share a box (lane = corner, then lane = slab / edge / coordinate), 32 boxes per pass of the block.  The grid is
+// built in LDS (the block has the word to itself): zeroed there, every box ORs its bit into the cells of its rectangle with LDS
+// atomics, and the finished cells leave as plain coalesced stores -- no memset launch in front, nothing to clean afterwards.
+// A box whose `enabled` byte is 0 (filter_visible_bboxes dropped it) gets an empty AABB and no cell.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double lpf_min8(double x)   // over the 8 lanes that share a box (contiguous, 8-aligned)
 {
@@ -1559,7 +1592,7 @@ __device__ __forceinline__ double lpf_max8(double x)
     x = fmax(x, __shfl_xor(x, 1)); x = fmax(x, __shfl_xor(x, 2)); return fmax(x, __shfl_xor(x, 4));
 }
 
-// 1 / x for the work-skipping structures only (float bounds, candidate cells: margins of 1e-5 and 2 pixels): the hardware
+// 1 / x for the work-skipping structures only (the float bounds: margin 1e-5): the hardware
 // reciprocal and one Newton step (~2^-50), a fifth of the IEEE division's chain
 __device__ __forceinline__ double lpf_rcp_approx(double x)
 {
@@ -1570,11 +1603,11 @@ __device__ __forceinline__ double lpf_rcp_approx(double x)
 __device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const int blk, char *s_raw)
 {
     // The work of a box is cut into short phases that hand their results on through LDS (lane = corner -> lane = slab ->
-    // lane = edge of the region -> lane = vertex): inside lpf_step_t the role has 72 registers, and the straight-line form
+    // lane = edge of the region -> lane = coordinate): inside lpf_step_t the role has 72 registers, and the straight-line form
     // (every lane everything: 111) spilled.  A block is one dependent chain with nothing beside it to hide latency, so the
     // chain is kept short: shared-reciprocal division where the reference's quotient is needed (lpf_div2, bit-equal to '/'),
     // approximate reciprocals where only the conservative structures are concerned, no square root -- and a block takes only 64
-    // boxes of its frame, ONE word of every grid cell: block blk = (frame blk / chunks, word blk % chunks), chunks = the
+    // boxes of its frame, ONE ground grid: block blk = (frame blk / chunks, word blk % chunks), chunks = the
     // words of the frame with the most boxes (a frame with fewer leaves its surplus blocks at once).
     LpfBoxJobLds &L = *reinterpret_cast<LpfBoxJobLds *>(s_raw);
     const int tid = threadIdx.x;
@@ -1587,16 +1620,13 @@ __device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const in
     const int words = (bf.B + 63) >> 6;
     if (wd >= words) return;
     const int b_lo = wd << 6, B = min(bf.B, b_lo + 64);     // this block's boxes: [b_lo, B)
-    // ---- word wd of every cell of the frame's grid starts empty: plain stores by this block, which is also the only one to
-    //      set bits in that word below (same CU, same L2: ordered by the barrier) -- no memset launch in front, nothing to clean
-    //      afterwards ----------------------------------------------------------------------------------------------------------
-    unsigned long long *__restrict__ gf = J.cand + bf.cand_off + wd;
+    // ---- the grid starts empty, and so do the bounds of the slots past the word's last box ----------------------------------------
+    unsigned long long *__restrict__ gf = J.cand + bf.cand_off + (size_t)wd * LPF_GRID_WORDS;
     {
-        const int ncell = J.cell_w * J.cell_h;
         int t0_ = tid;
         asm volatile("" : "+v"(t0_));
-        for (int i = t0_; i < ncell; i += LPF_BLOCK) gf[(size_t)i * words] = 0ull;
-        __threadfence_block();
+        for (int i = t0_; i < LPF_GRID_CELLS; i += LPF_BLOCK) L.grid[i] = 0ull;
+        L.bnd[t0_ >> 2][t0_ & 3] = (t0_ & 2) ? -INFINITY : INFINITY;
         __syncthreads();
     }
     for (int b0 = b_lo; b0 < B; b0 += 32) {
@@ -1735,48 +1765,56 @@ __device__ __forceinline__ void lpf_box_frame_block(const LpfBoxJob &J, const in
                     else q = (float)C[k < 4 ? 4 : 5][kk];
                 }
                 J.boxq[gb * 8 + k] = q;
-            }
-        }
-        // ---- phase 5, lane = vertex of the region: the image of the 8 vertices bounds the image of the region ---------------
-        bool everywhere = !bounded;
-        double u, w;
-        {
-            const double s0f = (k & 1) ? 1.0 : 0.0, s1f = (k & 2) ? 1.0 : 0.0, s2f = (k & 4) ? 1.0 : 0.0;
-            const double px = C[0][0] + s0f * C[1][0] + s1f * C[2][0] + s2f * C[3][0];
-            const double py = C[0][1] + s0f * C[1][1] + s1f * C[2][1] + s2f * C[3][1];
-            const double pz = C[0][2] + s0f * C[1][2] + s1f * C[2][2] + s2f * C[3][2];
-            const double cx = J.T[0] * px + J.T[1] * py + J.T[2] * pz + J.T[3];
-            const double cy = J.T[4] * px + J.T[5] * py + J.T[6] * pz + J.T[7];
-            const double cz = J.T[8] * px + J.T[9] * py + J.T[10] * pz + J.T[11];
-            const double qx = J.K[0] * cx + J.K[1] * cy + J.K[2] * cz;
-            const double qy = J.K[3] * cx + J.K[4] * cy + J.K[5] * cz;
-            const double d = J.K[6] * cx + J.K[7] * cy + J.K[8] * cz;
-            const bool bad = !(d > 1e-3) || !isfinite(qx) || !isfinite(qy);
-            if (__popcll(__ballot(bad) & gmask) != 0) everywhere = true;
-            const double rd = lpf_rcp_approx(d);
-            u = qx * rd; w = qy * rd;
-        }
-        double umin = lpf_min8(u), umax = lpf_max8(u), vmin = lpf_min8(w), vmax = lpf_max8(w);
-        int x0 = 0, x1 = J.cell_w - 1, y0 = 0, y1 = J.cell_h - 1;
-        if (!everywhere) {
-            umin -= 2.0; vmin -= 2.0; umax += 2.0; vmax += 2.0;                    // rounding of (u, v) + slack
-            if (umax < 0 || vmax < 0 || umin > J.W || vmin > J.H) { x0 = 1; x1 = 0; }           // never seen by a valid point
-            else {
-                x0 = umin <= 0 ? 0 : (int)umin >> J.cell_shift; y0 = vmin <= 0 ? 0 : (int)vmin >> J.cell_shift;
-                x1 = umax >= J.W ? J.cell_w - 1 : (int)umax >> J.cell_shift; y1 = vmax >= J.H ? J.cell_h - 1 : (int)vmax >> J.cell_shift;
-                x1 = min(x1, J.cell_w - 1); y1 = min(y1, J.cell_h - 1);
-            }
-        }
-        // ---- the box's bit into every cell of its rectangle: the 8 lanes of the box share the cells -------------------------------
-        if (live && on && x0 <= x1) {
-            const int nx = x1 - x0 + 1, nc = nx * (y1 - y0 + 1);
-            const unsigned long long bit = 1ull << (b & 63);
-            for (int i = k; i < nc; i += 8) {
-                const int yy = y0 + i / nx, xx = x0 + i % nx;
-                atomicOr(&gf[(size_t)(yy * J.cell_w + xx) * words], bit);
+                if (kk < 2) L.bnd[b - b_lo][(k >> 2) * 2 + kk] = q;
             }
         }
         __builtin_amdgcn_wave_barrier();                    // the slots are rewritten by the next pass
+    }
+    __syncthreads();
+    // ---- the domain: the (x, y) extent of the word's boxes that are on and bounded (one wave, lane = box) ---------------------------
+    if (tid < 64) {
+        const float lx = L.bnd[tid][0], ly = L.bnd[tid][1], hx = L.bnd[tid][2], hy = L.bnd[tid][3];
+        const bool in = lx <= hx && ly <= hy && isfinite(lx) && isfinite(ly) && isfinite(hx) && isfinite(hy);
+        float x0 = in ? lx : INFINITY, y0 = in ? ly : INFINITY, x1 = in ? hx : -INFINITY, y1 = in ? hy : -INFINITY;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, o)); y0 = fminf(y0, __shfl_xor(y0, o));
+            x1 = fmaxf(x1, __shfl_xor(x1, o)); y1 = fmaxf(y1, __shfl_xor(y1, o));
+        }
+        if (tid == 0) {
+            const float ex = x1 - x0, ey = y1 - y0;         // (no such box: -inf)
+            // cells of extent / LPF_GRID, but not under a metre: a tight group of parked cars would otherwise put every box into
+            // hundreds of cells (KITTI-360 annotates a moving car once per timestamp: dozens of boxes on the same few metres)
+            float ix = (ex > (float)LPF_GRID) ? (float)LPF_GRID / ex : 1.f, iy = (ey > (float)LPF_GRID) ? (float)LPF_GRID / ey : 1.f;
+            if (!(ix > 0.f)) ix = 0.f;                      // (an extent beyond the floats: one cell)
+            if (!(iy > 0.f)) iy = 0.f;
+            L.dom[0] = isfinite(x0) ? x0 : 0.f; L.dom[1] = isfinite(y0) ? y0 : 0.f; L.dom[2] = ix; L.dom[3] = iy;
+        }
+    }
+    __syncthreads();
+    // ---- every box into the cells of its rectangle: four lanes per box (off: lo > hi, no cell; unbounded: every cell) ---------------
+    {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int j = t_ >> 2, k = t_ & 3;
+        const float lx = L.bnd[j][0], ly = L.bnd[j][1], hx = L.bnd[j][2], hy = L.bnd[j][3];
+        if (lx <= hx && ly <= hy) {
+            const int x0 = lpf_ground_cell(lx, L.dom[0], L.dom[2]), x1 = lpf_ground_cell(hx, L.dom[0], L.dom[2]);
+            const int y0 = lpf_ground_cell(ly, L.dom[1], L.dom[3]), y1 = lpf_ground_cell(hy, L.dom[1], L.dom[3]);
+            const int nx = x1 - x0 + 1, nc = nx * (y1 - y0 + 1);
+            const unsigned long long bit = 1ull << j;
+            for (int i = k; i < nc; i += 4) {
+                const int yy = y0 + i / nx, xx = x0 + i - (i / nx) * nx;
+                atomicOr(&L.grid[yy * LPF_GRID + xx], bit);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        for (int i = t_; i < LPF_GRID_CELLS; i += LPF_BLOCK) gf[i] = L.grid[i];
+        if (t_ < 4) reinterpret_cast<float *>(gf + LPF_GRID_CELLS)[t_] = L.dom[t_];
     }
 }
 
