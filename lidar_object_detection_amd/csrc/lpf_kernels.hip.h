@@ -1220,7 +1220,12 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
         const int2 ent = lpf_tail_entry(P, tb - ncount);    // {first segment, frame << 3 | segments}
         const int f = ent.y >> 3, nw = ent.y & 7;
         const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
-        if (wave < nw && (P.valid_idx || P.inst_idx)) lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
+        if (wave < nw && (P.valid_idx || P.inst_idx)) {
+            // (1024-point segments -- small launches: the form that walks the 16 rows with lane = point; a dense row of a real scan
+            //  costs the other form 64 serial steps)
+            if (P.seg_pts == LPF_SEG_SMALL) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);
+            else lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
+        }
         return;
     }
     int first, f, nw, wd, part;
@@ -1441,7 +1446,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         const int per = b / plen, pos = b - per * plen;
         if (pos >= Y.kper) {                                // ---- tail of run i-1, then the mask pack (mode 4)
             const int tb = per * 8 + (pos - Y.kper);
-            if (tb < Y.ntail) { lpf_tail_block<PRE, 2>(Q, tb, s_raw); LPF_ROLE_END(tb < Q.nblk ? 2 : 3) }
+            if (tb < Y.ntail) { lpf_tail_block<PRE, 2>(Q, tb, s_raw); LPF_ROLE_END(tb < (Q.count_boxes ? Q.ncblk : 0) ? 3 : 2) }
             return;
         }
         vblk = ((per * (Y.kper >> 3) + (pos >> 3)) << 3) | (pos & 7);
