@@ -23,6 +23,7 @@
 // wide vs narrow: 4 frames = 108 blocks 21.5 vs 26.8 us; 8 frames 24.2 vs 29.2; 12 frames 29.3 vs 33.0; 20 frames = 540 blocks
 // 41.0 vs 40.6; 32 frames 55.8 vs 50.6)
 #define LPF_WIDE_BELOW 480
+#define LPF_FEW_BLOCKS 64           // list blocks of "a frame or two": see lpf_run_batch (count blocks in four parts, 16-row list wave)
 // Share of a step launch's K1 tiles (in twentieths) among which the previous run's tail blocks are dealt (see lpf_run_batch)
 #ifndef LPF_TAIL_SPREAD_20THS
 #define LPF_TAIL_SPREAD_20THS 13
@@ -203,7 +204,6 @@ void launch_tail(hipStream_t st, const LpfParams &P, int ntail, bool pre)
 // camera of that run
 void box_job_camera(const lpf_ctx *c, LpfBoxJob &J)
 {
-    memcpy(J.T, c->T, sizeof J.T);
     memcpy(J.K, c->K, sizeof J.K);
     J.W = c->W; J.H = c->H;
 }
@@ -1046,7 +1046,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // the list blocks, then -- when boxes are to be counted -- as many box-count blocks
     const bool count_boxes = M > 0 && Btot > 0;
     // (fused is decided further down; the same condition here)
-    const int csplit = (c->fused && !host_io && pts_on_device && !c->capturing && small) ? 4 : 1;     // count blocks per (group, word): see lpf_tail_block
+    int nblk_early = 0;
+    for (int f = 0; f < F; ++f) nblk_early += c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
+    // a frame or two of a real scan (up to 64 list blocks = 262 144 points): the launch is as long as its longest block, so the count
+    // blocks are cut in four and the lists use the 16-row wave.  Beyond that both cost more than they save (same box, us per step in a
+    // pipelined stream with / without: 20 real frames 29.8 / 25.5 with the cut, 25.2 / 25.5 with the list wave; one 2 M-point
+    // synthetic cloud 25.7 / 21.3 and 22.9 / 21.3, in order 42.4 / 38.9 with the list wave).
+    const bool few = small && nblk_early <= LPF_FEW_BLOCKS;
+    const int csplit = (c->fused && !host_io && pts_on_device && !c->capturing && few) ? 4 : 1;     // count blocks per (group, word): see lpf_tail_block
     int nblk = 0, ncblk = 0;                               // list blocks; box-count blocks: one per group of segments, 64-box word and part
     for (int f = 0; f < F; ++f) {
         const int nb = c->h_frames[f].nseg > 0 ? (c->h_frames[f].nseg + LPF_LISTS_WAVES - 1) / LPF_LISTS_WAVES : 1;
@@ -1144,7 +1151,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_tab = (uint4 *)S.seg_tab.p; P.grp_tab = (uint4 *)S.grp_tab.p; P.frm_tab = (uint4 *)S.frm_tab.p;
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.cnt = (unsigned *)S.cnt.p;
-    P.nblk = nblk; P.ncblk = ncblk; P.csplit = csplit; P.count_boxes = count_boxes ? 1 : 0;
+    P.nblk = nblk; P.ncblk = ncblk; P.csplit = csplit; P.lists_small = few ? 1 : 0; P.count_boxes = count_boxes ? 1 : 0;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;

@@ -64,6 +64,7 @@ struct LpfParams {
     const int2 *blks;            // [nblk] list blocks of the tail: {first segment, frame << 3 | segments (0..4)}
     const int4 *cblks;           // [ncblk] box-count blocks: {first segment, frame, candidate word, segments (0..4)}
     int nblk, ncblk;
+    int lists_small;             // narrow tail blocks build their lists with the 16-row wave (small launches of dense real scans)
     int csplit;                  // count blocks per (group of segments, word): they share the group's chunks of 64 masked points (1, or 4 in small
                                  // software-pipelined launches, whose longest chain is a count block on a car)
     const float4 *pts;
@@ -1223,7 +1224,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
         if (wave < nw && (P.valid_idx || P.inst_idx)) {
             // (1024-point segments -- small launches: the form that walks the 16 rows with lane = point; a dense row of a real scan
             //  costs the other form 64 serial steps)
-            if (P.seg_pts == LPF_SEG_SMALL) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);
+            if (P.lists_small) lpf_lists_wave_small<PRE>(P, fr, ent.x + wave);
             else lpf_lists_wave<PRE, STEP>(P, fr, ent.x + wave, LL.lidx[wave]);
         }
         return;
@@ -1389,7 +1390,7 @@ struct LpfBoxJob {               // one box preparation / table set-up (lpf_box_
     const uint8_t *enabled_in;   // velodyne-frame input: [Btot] 0 = dropped earlier by filter_visible_bboxes, or null
     int cam0, filter_visible, oriented, F;
     double Tcv[12];              // rows 0..2 of inv(TrVeloToCam) (cam0 = 1)
-    double T[12], K[9];          // TrVeloToRect rows 0..2, camera.K[:3,:3]
+    double K[9];                 // camera.K[:3,:3] (the visibility filter of cam-0 boxes)
     int W, H, chunks;            // chunks: blocks per frame = 64-bit words of the frame with the most boxes
     const LpfBoxFrame *bframes;  // [F] (F > 1)
     LpfBoxFrame frame0;          // ... by value for one frame

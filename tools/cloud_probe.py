@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] literally -- ONE synthetic cloud (default 2 000 000 points, 8 disk masks, 32 boxes, depth < 30) per launch
+set, six resident clouds in turn, every step with its own masks and boxes: microseconds per step in order and as a software-
+pipelined stream.  usage: python tools/cloud_probe.py [points]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from lidar_object_detection_amd import synthetic as S  # noqa: E402
+from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+M, B = 8, 32
+dev = torch.device("cuda", 0)
+TrVeloToCam, T, K, W, H = S.default_calibration()
+Tcv = np.linalg.inv(TrVeloToCam)
+bufs = []
+for i in range(6):
+    sc = S.scene(n, M, B, seed=7000 + i)
+    o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+             valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((1, n), dtype=torch.int64, device=dev),
+             count_mb=torch.zeros(M * B, dtype=torch.int32, device=dev), summary=torch.zeros(SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+    bufs.append((torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev), o,
+                 torch.from_numpy(np.ascontiguousarray(sc["corners_cam0"])).to(dev)))
+torch.cuda.synchronize(dev)
+res = []
+for mode in (False, "fused-pack"):
+    with LpfContext(0) as ctx:
+        ctx.set_pipelined(mode)
+        ctx.set_camera(T, K, W, H, 0.0, 30.0)
+        fns = [ctx.make_device_step(p_, np.array([0, n], np.int64), masks_u8=m_, lend=True, boxes_cam0=c_, box_off=np.array([0, B], np.int32),
+                                    T_cam_to_velo=Tcv, inst_cap=n, **o) for p_, m_, o, c_ in bufs]
+        for _ in range(10):
+            for f in fns:
+                f()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            for f in fns:
+                f()
+        ctx.sync()
+        res.append(1e6 * (time.perf_counter() - t0) / 600)
+print("one %d-point cloud per launch set (8 masks, 32 boxes, own masks and boxes every step): in order %.1f us, pipelined stream %.1f us per step" % (n, res[0], res[1]), flush=True)
