@@ -188,3 +188,52 @@ def test_mode_switch_with_lent_masks_waiting(calib):
                 assert "masks" in str(e)
             else:
                 assert np.array_equal(r["label_bits"], ref["label_bits"]) and np.array_equal(r["count_mb"], ref["count_mb"])
+
+
+def test_lab_role_clock_sees_every_role_of_a_pipelined_stream(calib):
+    """Lab build: lpf_lab_role_clock (tools/role_clock.py) counts the blocks of every role of the step launches -- one summary block,
+    one box-job block per 64 boxes, the frame's list and box-count blocks (in four parts: a single frame) and its tiles per run --
+    and the results are those of the product library."""
+    import torch
+    from conftest import lab_library
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    lab = lab_library()
+    if lab is None:
+        pytest.skip("liblpf_lab.so has not been built (python -m lidar_object_detection_amd._build lab)")
+    TrVeloToCam, T, K, W, H = S.default_calibration(calib)
+    Tcv = np.linalg.inv(TrVeloToCam)
+    n, M, B = 50_000, 4, 70                                 # 49 segments of 1024 points: 13 list blocks, 2 words of boxes
+    sc = S.scene(n, n_masks=M, n_boxes=B, seed=3)
+    dev = torch.device("cuda", 0)
+    d_pts, d_masks = torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev)
+    d_cam0 = torch.from_numpy(np.ascontiguousarray(sc["corners_cam0"])).to(dev)
+    runs, outs = 12, {}
+    for lib in (None, lab):
+        o = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(n, dtype=torch.int32, device=dev),
+                 valid_idx=torch.empty(n, dtype=torch.int64, device=dev), inst_idx=torch.empty((1, n), dtype=torch.int64, device=dev),
+                 count_mb=torch.zeros(M * B, dtype=torch.int32, device=dev), summary=torch.zeros(SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        with LpfContext(0, library=lib) as ctx:
+            ctx.set_pipelined("fused-pack")
+            ctx.set_camera(T, K, W, H, 0.0, 40.0)
+            fn = ctx.make_device_step(d_pts, np.array([0, n], np.int64), masks_u8=d_masks, lend=True, boxes_cam0=d_cam0,
+                                      box_off=np.array([0, B], np.int32), T_cam_to_velo=Tcv, inst_cap=n, **o)
+            if lib is not None:
+                assert ctx.role_clock(reset=True) == {}     # switched on; nothing has run
+            for _ in range(runs):
+                fn()
+            clk = ctx.role_clock() if lib is not None else None      # (synchronises: the pipeline is drained)
+            ctx.sync()
+        outs[lib] = {k: v.cpu().numpy().copy() for k, v in o.items()}
+    nv = int(np.frombuffer(outs[None]["summary"].tobytes(), SUMMARY_DTYPE)[0]["n_valid"])
+    assert 0 < nv < n
+    for k in ("uv", "label_bits", "count_mb", "summary"):
+        assert np.array_equal(outs[None][k], outs[lab][k]), k
+    assert np.array_equal(outs[None]["valid_idx"][:nv], outs[lab]["valid_idx"][:nv])        # (beyond n_valid: never written)
+    nseg = (n + 1023) // 1024
+    nlist = (nseg + 3) // 4
+    assert clk["summaries"]["blocks"] == runs and clk["box job"]["blocks"] == 2 * runs, clk
+    assert clk["lists"]["blocks"] == nlist * runs and clk["box counts"]["blocks"] == nlist * 2 * 4 * runs, clk
+    assert clk["project+label tiles"]["blocks"] == 2 * nseg * runs, clk      # 512-point tiles
+    for r in clk.values():
+        assert 0.0 < r["mean_us"] <= r["longest_us"] < 1e4, clk
