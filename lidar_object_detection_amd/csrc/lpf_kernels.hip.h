@@ -1232,6 +1232,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     int first, f, nw, wd, part;
     lpf_count_entry(P, tb, first, f, nw, wd, part);
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
+    if (wd * LPF_BC_WORD >= fr.B) return;                   // a frame without boxes in a batch that has some: no grid to look into (block-uniform)
     lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.dom);
     {                                                       // the block's (up to) four segments: row prefixes -> LDS
         const int lane = lpf_lane();
@@ -1305,6 +1306,7 @@ __global__ __launch_bounds__(64 * LPF_WIDE_WAVES) void lpf_tail_wide_t(const Lpf
     int first, f, nw, wd, part;
     lpf_count_entry(P, tb, first, f, nw, wd, part);           // (part is always 0 here: the wide form shares over its own 16 waves)
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
+    if (wd * LPF_BC_WORD >= fr.B) return;                   // (as in lpf_tail_block)
     if (wave < LPF_LISTS_WAVES) {                           // the block's (up to) four segments: row prefixes -> LDS
         unsigned im = 0, mbase = 0, L = 0;
         if (wave < nw) L = lpf_count_rows(P, fr, first + wave, im, mbase);

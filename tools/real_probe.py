@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """146 real frames per step (the four full-size golden frames in turn, ~16.9 M points): in-order steps for a kernel trace.
-usage: rocprofv3 --kernel-trace --stats ... -- python3 tools/real_probe.py [serial|fused|fused-pack] [noboxes|nolists|nomasks] [frames]"""
+usage: rocprofv3 --kernel-trace --stats ... -- python3 tools/real_probe.py [serial|fused|fused-pack] [noboxes|nolists|nomasks|-] [frames] [geometry: lab build]"""
 import os
 import sys
 import time
@@ -15,6 +15,9 @@ from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE  # noqa
 mode = sys.argv[1] if len(sys.argv) > 1 else "serial"
 lab = sys.argv[2] if len(sys.argv) > 2 else ""
 nfr = int(sys.argv[3]) if len(sys.argv) > 3 else 146
+geometry = sys.argv[4] if len(sys.argv) > 4 else ""
+if lab == "-":
+    lab = ""
 dev = torch.device("cuda", 0)
 gdir = os.path.join(ROOT, "tests", "golden")
 cal = np.load(os.path.join(gdir, "calib_cam0.npz"))
@@ -39,7 +42,10 @@ o = dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev), label_bits=to
          inst_idx=None if lab == "nolists" else torch.empty((nfr, cap), dtype=torch.int64, device=dev),
          count_mb=torch.zeros(M * int(boff[-1]), dtype=torch.int32, device=dev), summary=torch.zeros(nfr * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
 torch.cuda.synchronize(dev)
-with LpfContext(0) as ctx:
+from lidar_object_detection_amd import _build  # noqa: E402
+with LpfContext(0, library=_build.LAB_LIB if geometry else None) as ctx:
+    if geometry:
+        ctx.set_geometry(geometry)
     ctx.set_pipelined(False if mode == "serial" else mode)
     ctx.set_camera(T, K, W, H, 0.0, 50.0)
     fn = ctx.make_device_step(d_pts, off, masks_u8=None if lab == "nomasks" else d_masks, lend=True, boxes_cam0=None if lab == "noboxes" else d_cam0,
@@ -52,6 +58,6 @@ with LpfContext(0) as ctx:
     for _ in range(reps):
         fn()
     ctx.sync()
-    print("%s %s frames=%d points=%d: %.1f us per step" % (mode, lab or "all", nfr, ntot, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
+    print("%s %s %s frames=%d points=%d: %.1f us per step" % (mode, lab or "all", geometry, nfr, ntot, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
     sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
     print("valid %d masked %d list entries %d" % (sm["n_valid"].sum(), sm["n_labelled"].sum(), sm["inst_count"].sum()))
