@@ -24,6 +24,8 @@ def _plan(shape, k):
         return [60_000 + 7_919 * k], [3 + 4 * k]
     if shape == "three_frames_fixed":
         return [30_000, 1_000, 52_000], [6, 9, 4]
+    if shape == "two_frames_many_boxes":                    # two and three 64-box words: a ground grid and (a frame or two) four count blocks each
+        return [40_000 + 1_500 * k, 25_000], [70 + 3 * k, 0 if k == 5 else 130]
     return [30_000 + 4_097 * k, 1 + k, 70_000 - 5_000 * k], [6 + k, 0 if k == 2 else 9, 4 + 2 * k]     # three_frames_varying
 
 
@@ -35,7 +37,7 @@ def _outputs(torch, dev, F, n, cap, Btot, summary_bytes):
 
 
 @pytest.mark.parametrize("boxes", ["host_velo", "device_velo_lent", "device_cam0_lent", "device_cam0_copied"])
-@pytest.mark.parametrize("shape", ["one_frame_varying", "three_frames_fixed", "three_frames_varying"])
+@pytest.mark.parametrize("shape", ["one_frame_varying", "three_frames_fixed", "three_frames_varying", "two_frames_many_boxes"])
 @pytest.mark.parametrize("mode", ["fused", "fused-pack"])
 def test_boxes_masks_and_shape_change_every_run(calib, mode, shape, boxes):
     import torch
@@ -92,7 +94,7 @@ def test_boxes_masks_and_shape_change_every_run(calib, mode, shape, boxes):
         ctx.sync()
     assert st["host_waits"] == 0 and st["drains"] == 0 and st["blocking_uploads"] == 0, st
     assert st["step_launches"] == nruns and st["box_jobs_riding"] == nruns and st["box_jobs_alone"] == 0, st
-    if shape != "three_frames_varying":
+    if shape not in ("three_frames_varying", "two_frames_many_boxes"):       # (their frame sizes / box counts change: tables travel)
         assert st["uploads"] == (nruns if boxes == "host_velo" else 0), st      # one frame / an unchanged shape: no table travels
     for r in runs:
         o = r["o"]
