@@ -208,7 +208,7 @@ def time_steps(torch, dev, fns, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps
 
 
-def secondary_lines(torch, dev, local_rank, T, K, W, H):
+def secondary_lines(torch, dev, local_rank, T, K, W, H, use_rects=True):
     """The other BASELINE.json configs on this GPU, same process, each checked before it is timed.  As in the reference's frame
     loop (V3:556-562) every step brings its own boxes -- cam-0 corners lent in HBM, prepared on the device inside the step."""
     from lidar_object_detection_amd import synthetic as S
@@ -233,11 +233,12 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
         for sc in scs:
             o = make_outputs(torch, dev, n, 1, n, N_MASKS, N_BOXES, SUMMARY_DTYPE.itemsize)
             bufs.append((torch.from_numpy(sc["points"]).to(dev), torch.from_numpy(sc["masks"][None]).to(dev), o,
-                         torch.from_numpy(np.ascontiguousarray(sc["corners_cam0"])).to(dev)))
+                         torch.from_numpy(np.ascontiguousarray(sc["corners_cam0"])).to(dev),
+                         None))
         off = np.array([0, n], np.int64)
         boff = np.array([0, N_BOXES], np.int32)
-        fns = [ctx.make_device_step(p_, off, masks_u8=m_, lend=True, boxes_cam0=c_, box_off=boff, T_cam_to_velo=Tcv, inst_cap=n, **o)
-               for p_, m_, o, c_ in bufs]
+        fns = [ctx.make_device_step(p_, off, masks_u8=m_, lend=True, boxes_cam0=c_, box_off=boff, T_cam_to_velo=Tcv, inst_cap=n, mask_rects=r_, **o)
+               for p_, m_, o, c_, r_ in bufs]
         sync()
 
         def check2(what):
@@ -303,7 +304,8 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             d = dict(F=Fb, sizes=sizes, off=offb, boff=boffb, M=Mb, ntot=int(offb[-1]), cap=max(sizes),
                      pts=torch.from_numpy(np.concatenate([fr["points"] for fr in frames])).to(dev),
                      masks=torch.from_numpy(np.stack([fr["masks"] for fr in frames])).to(dev),
-                     cam0=torch.from_numpy(np.concatenate([fr["cam0"] for fr in frames])).to(dev))
+                     cam0=torch.from_numpy(np.concatenate([fr["cam0"] for fr in frames])).to(dev),
+                     rects=torch.from_numpy(LpfContext.mask_rects(np.stack([fr["masks"] for fr in frames]))).to(dev))
             d["o"] = dict(uv=torch.empty((d["ntot"], 2), dtype=torch.int32, device=dev), label_bits=torch.empty(d["ntot"], dtype=torch.int32, device=dev),
                           valid_idx=torch.empty(d["ntot"], dtype=torch.int64, device=dev),
                           inst_idx=torch.empty((Fb, d["cap"]), dtype=torch.int64, device=dev),
@@ -324,9 +326,9 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             d["check"] = check
             return d
 
-        def stepper(ctx, d):
+        def stepper(ctx, d, rects=False):
             return ctx.make_device_step(d["pts"], d["off"], masks_u8=d["masks"], lend=True, boxes_cam0=d["cam0"], box_off=d["boff"],
-                                        T_cam_to_velo=Tcv_g, filter_visible=True, inst_cap=d["cap"], **d["o"])
+                                        T_cam_to_velo=Tcv_g, filter_visible=True, inst_cap=d["cap"], mask_rects=d["rects"] if rects else None, **d["o"])
 
         def fused_loop(ctx, fns_, checks, reps):
             """the same steps in a loop under the software-pipelined mode (a stream of batches: throughput, not latency)"""
@@ -384,7 +386,7 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
             if len(full) == 4:
                 nfr = 146
                 dbs = [batch_of([full[(i + s_) % 4] for i in range(nfr)]) for s_ in range(2)]     # two resident batches (2 x 270 MB of points)
-                fns = [stepper(ctx, d) for d in dbs]
+                fns = [stepper(ctx, d, use_rects) for d in dbs]      # with the masks' 2D rectangles (lpf_set_mask_rects), as a detector gives them
                 sync()
                 for f_ in fns:
                     f_()
@@ -408,13 +410,27 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
                 time_steps(torch, dev, fns, 100, 0, lambda: (ctx.sync(), sync()))
                 ms, cnt = ctx.profile_read(reset=True)
                 ctx.profile_enable(False)
+                dt_plain = None
+                if use_rects:                               # the same stream without the masks' rectangles (every mask byte read)
+                    fns_plain = [stepper(ctx, d, False) for d in dbs]
+                    for _ in range(3):
+                        for f_ in fns_plain:
+                            f_()
+                    ctx.sync()
+                    for d in dbs:
+                        d["check"]("secondary real scans at headline size, pipelined, no mask rectangles")
+                    dt_plain = time_steps(torch, dev, fns_plain, 100, 10, lambda: (ctx.sync(), sync()))
+                    del fns_plain
                 ctx.set_pipelined(False)
                 sm = np.frombuffer(dbs[0]["o"]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
                 nv, nl = int(sm["n_valid"].sum()), int(sm["inst_count"].sum())
                 br = 1e-3 * ms / max(cnt, 1)
                 # itemised: + the masks read and the label images written by the riding pack (5 masks x 1408 x 376 bytes per frame:
                 # 2.6 MB of masks next to 3.2 MB of strict point traffic per frame), the label look-ups, valid_idx, the lists
-                item = ALGO_BYTES_PER_POINT * ntot_r + nfr * (dbs[0]["M"] + 1) * Wg * Hg + 12 * nv + 8 * nl
+                rect_bytes = int(sum(int(((r[:, :, 2] - r[:, :, 0]) * (r[:, :, 3] - r[:, :, 1])).sum()) for r in [dbs[0]["rects"].cpu().numpy().astype(np.int64)]))
+                mask_read = rect_bytes if use_rects else nfr * dbs[0]["M"] * Wg * Hg       # (with the rectangles only what lies inside them is read)
+                item = ALGO_BYTES_PER_POINT * ntot_r + mask_read + nfr * Wg * Hg + 12 * nv + 8 * nl
+                item_plain = ALGO_BYTES_PER_POINT * ntot_r + nfr * (dbs[0]["M"] + 1) * Wg * Hg + 12 * nv + 8 * nl
                 out["real_scans_at_headline_size"] = {
                     "frames_per_step": nfr, "points_per_step": ntot_r, "valid_fraction": nv / ntot_r, "masked_list_entries_per_step": nl,
                     "boxes_given_per_step": int(dbs[0]["boff"][-1]), "boxes_change_every_step": True, "mode": "fused-pack",
@@ -424,8 +440,13 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H):
                     "strict_frac_of_hbm_peak_step_kernel": ALGO_BYTES_PER_POINT * ntot_r / br / 1e9 / HBM_PEAK_GBS,
                     "itemised_bytes_per_step": item, "itemised_frac_of_hbm_peak": item / dt_r / 1e9 / HBM_PEAK_GBS,
                     "mask_bytes_per_step": nfr * dbs[0]["M"] * Wg * Hg,
+                    "mask_rectangles_given": bool(use_rects),
+                    "mask_bytes_inside_the_rectangles_per_step": rect_bytes,
+                    "us_per_step_without_mask_rectangles": None if dt_plain is None else 1e6 * dt_plain,
+                    "itemised_frac_of_hbm_peak_without_mask_rectangles": None if dt_plain is None else item_plain / dt_plain / 1e9 / HBM_PEAK_GBS,
                     "why_below_the_synthetic_headline": "a real frame brings 2.6 MB of masks for 3.2 MB of strict point traffic (the synthetic "
-                                                        "cloud: 4.2 MB for 56 MB), its tail works on 5 x the valid and masked points per input point, "
+                                                        "cloud: 4.2 MB for 56 MB; with the masks' 2D rectangles only the 42 KB inside them are read, the "
+                                                        "0.5 MB label image is still written), its tail works on 5 x the valid and masked points per input point, "
                                                         "and half of these frames carry 186 / 314 annotated boxes; per-kernel split: "
                                                         "profiles/r03_real146_kernel_stats_*.csv, DESIGN.md section 8",
                     "host_waits_and_drains_in_the_pipelined_stream": [st["host_waits"] - 2, st["drains"] - 2],
@@ -563,6 +584,7 @@ def main():
                     help="keep the GPU busy with untimed steps for this long before the W warm-up steps: after the seconds of host-side "
                          "set-up the GPU's clocks are down, and they take tens of milliseconds of load to come back (the same kernel "
                          "averages 95 us in the first 30 ms and 92 us afterwards; 0 = off)")
+    ap.add_argument("--mask-rects", action="store_true", help="also pass the masks' 2D rectangles (lpf_set_mask_rects); measured: no change on this workload, whose pack hides behind the tiles (the real-scan line of `secondary` reports both)")
     ap.add_argument("--static-boxes", action="store_true", help="set the boxes once instead of with every step (the reference's loop "
                                                                 "builds a new box list per frame: V3:556-562)")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' runs the multi-rank path without RCCL")
@@ -616,6 +638,10 @@ def main():
     scenes = [S.scene(n, N_MASKS, N_BOXES, seed=1000 * rank + f) for f in range(F)]
     base_pts = torch.from_numpy(np.concatenate([sc["points"] for sc in scenes], axis=0)).to(dev)
     masks0 = torch.from_numpy(np.stack([sc["masks"] for sc in scenes])).to(dev)           # [F,8,H,W] u8
+    # the masks' 2D rectangles, as a detector hands them out beside its masks (cvs_erosion.py:86-87, 110): outside them the masks are zero
+    use_rects = bool(args.mask_rects)
+    rects0 = torch.from_numpy(LpfContext.mask_rects(np.stack([sc["masks"] for sc in scenes]))).to(dev)     # [F,8,4] int32
+    rects_dev = []
     pts_dev, masks_dev, outs, cam0_host, cam0_dev, velo_ref, keep_ref = [], [], [], [], [], [], []
     for b in range(nbuf):
         if b == 0:
@@ -625,6 +651,7 @@ def main():
             pts_dev.append(base_pts[perm].contiguous())
             del perm
         masks_dev.append(masks0.clone() if b else masks0)
+        rects_dev.append(rects0.clone() if b else rects0)
         outs.append(make_outputs(torch, dev, ntot, F, ntot, N_MASKS, F * N_BOXES, SUMMARY_DTYPE.itemsize))
         bb = b if per_step_boxes else 0
         cam = [scenes[f]["corners_cam0"] if bb == 0 else S.synthetic_boxes(N_BOXES, seed=500_000 * bb + 1000 * rank + f)[0] for f in range(F)]
@@ -656,7 +683,8 @@ def main():
         nb = nbuf
         steps_fn = [ctx.make_device_step(pts_dev[b], frame_off, masks_u8=None if args.lab == "nomasks" else masks_dev[b], lend=True,
                                          boxes_cam0=cam0_dev[b] if per_step_boxes else None, box_off=box_off, T_cam_to_velo=Tcv,
-                                         filter_visible=True, inst_cap=n, **outs[b])
+                                         filter_visible=True, inst_cap=n, mask_rects=rects_dev[b] if use_rects and args.lab != "nomasks" else None,
+                                         **outs[b])
                     for b in range(nb)]
 
         def drain():                                        # pipelined modes: launch what the last runs still owe, then wait
@@ -755,7 +783,7 @@ def main():
                                       else "boxes set once"),
                        "clouds_per_step_per_gpu": F, "points_per_cloud": n, "points_per_step_per_gpu": ntot,
                        "masks": N_MASKS, "boxes": N_BOXES, "boxes_change_every_step": bool(per_step_boxes),
-                       "masks_change_every_step": True, "resident_batches_per_gpu": nbuf, "mode": args.mode,
+                       "masks_change_every_step": True, "mask_rectangles_given": bool(use_rects), "resident_batches_per_gpu": nbuf, "mode": args.mode,
                        "clock_preheat_ms_before_the_warmup_steps": args.preheat_ms,
                        "host_while_queueing_the_timed_steps": main_run["queued"],
                        "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 5          /* 2: lpf_outputs gained uv_valid / label_valid
+#define LPF_ABI_VERSION 6          /* 2: lpf_outputs gained uv_valid / label_valid
                                       3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
                                          lpf_set_pipelined modes; stale graphs are refused
                                       4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4)
@@ -40,7 +40,8 @@ extern "C" {
                                          the run's launch; on_device = 2 = lent corners in lpf_set_boxes_ex / lpf_set_boxes_cam0);
                                          geometry tables per run (a new batch shape no longer drains the pipeline);
                                          lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
-                                         section 8); lpf_set_geometry only in lab builds (-DLPF_LAB) */
+                                         section 8); lpf_set_geometry only in lab builds (-DLPF_LAB)
+                                      6: lpf_set_mask_rects (added; nothing else changed) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -175,6 +176,15 @@ int lpf_set_camera(lpf_ctx *ctx, const double T_velo_to_rect[16], const double K
  *   modes (lpf_set_pipelined 2 / 4) leave lent masks to the next lpf_run* in the same way: a small launch's tiles read
  *   them directly, a large one packs them (mode 4: by blocks of its own launch, see there).  Same results. */
 int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode_iters, int on_device);
+/* Optional hint for the NEXT lpf_set_masks_* call with the same F and M: rects[F][M][4] = {x0, y0, x1, y1} (int32, pixels, half
+ * open) -- the caller's word that mask m of frame f is zero outside its rectangle.  A detector hands out every mask with its 2D box
+ * and crops the mask to it (the reference's segmenter returns them side by side, cvs_erosion.py:86-87, 110: `boxes`, `masks`); a real
+ * frame's masks are a few per cent non-zero.  Where uint8 masks are packed as they are (no erosion; every mode) the pack then reads
+ * only the 16-pixel groups that meet a mask's rectangle: the same results as without the hint as long as the caller's word holds;
+ * every other form (float masks, erosion, small launches whose tiles read the masks themselves) ignores it.  on_device: 0 = host
+ * memory, copied now without a wait; otherwise device memory (16-byte aligned) that is read when the masks are packed -- it must stay
+ * unchanged until then, like lent masks.  rects = NULL clears a pending hint.  The hint is consumed by the next lpf_set_masks_*. */
+int lpf_set_mask_rects(lpf_ctx *ctx, const int32_t *rects, int on_device, int F, int M);
 int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int binarize,
                       int erode_iters, int on_device);
 /* Pre-packed label images [F][H][W] (bit m = mask m). */

@@ -89,6 +89,7 @@ def load(path=None):
     lib.lpf_allreduce_metrics.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, _P]
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.lpf_set_mask_rects.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_label_image.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_get_label_image.argtypes = [_P, _P, ctypes.c_int]
@@ -122,7 +123,7 @@ def load(path=None):
 EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
             "lpf_release_to_stream", "lpf_sync",
             "lpf_set_pipelined", "lpf_allreduce_metrics",
-            "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_label_image",
+            "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_mask_rects", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
@@ -393,6 +394,44 @@ class LpfContext:
         self.W, self.H = int(width), int(height)
 
     BINARIZE = {"astype": 0, "v3": 1, "gt0.5": 2}
+
+    def set_mask_rects(self, rects):
+        """Hint for the NEXT set_masks call: rects int32 [M,4] or [F,M,4] = (x0, y0, x1, y1), half open, pixels -- mask m of frame f is
+        zero outside its rectangle (a detector's masks come cropped to their 2D boxes).  Where uint8 masks are packed as they are the
+        pack then only reads what lies inside; anything else ignores the hint; results do not change as long as the word holds.  NumPy
+        array (copied now) or an int32 torch GPU tensor (read when the masks are packed: keep it unchanged until then).  None clears."""
+        if rects is None:
+            self._check(self._lib.lpf_set_mask_rects(self._h, None, 0, 0, 0))
+            return
+        dev = _is_torch(rects)
+        shape = tuple(rects.shape)
+        if len(shape) == 2:
+            shape = (1,) + shape
+        if len(shape) != 3 or shape[2] != 4:
+            raise ValueError("rects must be [M,4] or [F,M,4], got %s" % (shape,))
+        if dev:
+            if str(rects.dtype) != "torch.int32" or not rects.is_contiguous():
+                raise ValueError("device rects must be a contiguous int32 tensor")
+            self._lent.append(rects)
+            self._check(self._lib.lpf_set_mask_rects(self._h, _dev_ptr(rects), 1, shape[0], shape[1]))
+        else:
+            a = np.ascontiguousarray(rects, dtype=np.int32)
+            self._check(self._lib.lpf_set_mask_rects(self._h, a.ctypes.data, 0, shape[0], shape[1]))
+
+    @staticmethod
+    def mask_rects(masks):
+        """Tight rectangles [..., M, 4] (x0, y0, x1, y1; half open; an empty mask gets 0, 0, 0, 0) of host masks [..., M, H, W]: what a
+        detector's 2D boxes give for masks cropped to them."""
+        m = np.asarray(masks) != 0
+        ys, xs = m.any(axis=-1), m.any(axis=-2)
+        def span(b):
+            any_ = b.any(axis=-1)
+            lo = np.where(any_, b.argmax(axis=-1), 0)
+            hi = np.where(any_, b.shape[-1] - b[..., ::-1].argmax(axis=-1), 0)
+            return lo, hi
+        y0, y1 = span(ys)
+        x0, x1 = span(xs)
+        return np.stack([x0, y0, x1, y1], axis=-1).astype(np.int32)
 
     def set_masks(self, masks, erode_iters=0, v3_pipeline=False, binarize=None, lend=False):
         """masks: [M,H,W] or [F,M,H,W]; uint8/bool (nonzero = member) or float32 (reference masks).
@@ -678,7 +717,7 @@ class LpfContext:
                                             ctypes.byref(o)))
 
     def make_device_step(self, pts, frame_off, masks_u8=None, erode_iters=0, lend=False, boxes_cam0=None, box_off=None,
-                         T_cam_to_velo=None, filter_visible=True, oriented=True, **outs):
+                         T_cam_to_velo=None, filter_visible=True, oriented=True, mask_rects=None, **outs):
         """Pre-marshal one device-mode step -- optional u8 masks, optional per-step boxes (the reference's per-frame box
         preparation from cam-0 corners, V3:556-562), run_batch -- and return a zero-argument callable that only performs the C
         calls: for launch-bound loops.
@@ -686,7 +725,8 @@ class LpfContext:
         launch of its own at the call).  lend=True passes masks (and box corners) as LENT (on_device = 2): nothing is copied or
         packed at the call -- in the "fused-pack" mode the pack and the box set-up ride in the step's launch, small sparse launches
         read the masks directly -- but the tensors must then stay UNCHANGED until the step's results are complete (in the
-        pipelined modes a step's inputs are read up to two launches later)."""
+        pipelined modes a step's inputs are read up to two launches later).
+        mask_rects: int32 torch GPU tensor [F,M,4], the masks' rectangles (set_mask_rects), lent like the masks."""
         off = np.ascontiguousarray(frame_off, dtype=np.int64)
         F = off.shape[0] - 1
         o = Outputs()
@@ -716,6 +756,12 @@ class LpfContext:
             p_m, M, it = _P(_dev_ptr(masks_u8)), shape[1], int(erode_iters)
             self.F_masks, self.M = F, M
             keep.append(masks_u8)
+            if mask_rects is not None:
+                if tuple(mask_rects.shape) != (F, M, 4) or str(mask_rects.dtype) != "torch.int32" or not mask_rects.is_contiguous():
+                    raise ValueError("mask_rects must be a contiguous torch.int32 GPU tensor [F,M,4]")
+                p_r, setr = _P(_dev_ptr(mask_rects)), lib.lpf_set_mask_rects
+                keep.append(mask_rects)
+                calls.append(lambda: setr(h, p_r, 1, F, M))
             calls.append(lambda: setm(h, p_m, F, M, it, where))
         if boxes_cam0 is not None:
             boff = np.ascontiguousarray(box_off, dtype=np.int32)

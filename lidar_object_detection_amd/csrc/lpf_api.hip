@@ -70,7 +70,7 @@ struct lpf_ctx {
     DevBuf mask_stage;
     // Masks not packed yet (serial mode, no erosion, host masks in mask_stage or device masks the caller lends: on_device 2):
     // a small launch reads them directly in K1 (LpfDirect), anything else packs them first (ensure_packed).
-    struct Lazy { bool valid = false; const void *p = nullptr; bool f32 = false; int mode = 0; } lazy;
+    struct Lazy { bool valid = false; const void *p = nullptr; bool f32 = false; int mode = 0; const int4 *rects = nullptr; } lazy;
 
     // Boxes.  A ring of box sets: in the software-pipelined modes the tail that counts into the boxes of run i executes one
     // or two launches after run i was queued, so a lpf_set_boxes* for the NEXT run must not touch the tables run i's tail is
@@ -133,10 +133,12 @@ struct lpf_ctx {
     bool defer = false;
     // Lent masks of a software-pipelined context that have not been packed: the next run decides -- a small launch reads them
     // directly, a large one in mode 4 lets their pack ride in its launch (uint8, 16-byte aligned planes), anything else packs now.
-    struct Ride { bool valid = false; const void *masks = nullptr; bool f32 = false, can_ride = false; int mode = 0, F = 0, M = 0; void *label = nullptr; } ride;
+    struct Ride { bool valid = false; const void *masks = nullptr; bool f32 = false, can_ride = false; int mode = 0, F = 0, M = 0; void *label = nullptr; const int4 *rects = nullptr; } ride;
     // lpf_get_stats: [0] host waits, [1] drains (owed work launched outside a run), [2] uploads through the pinned ring, [3] step
     // launches, [4] box jobs launched as a kernel of their own, [5] box jobs that rode in a step launch, [6] blocking uploads
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // lpf_set_mask_rects: rectangles for the NEXT lpf_set_masks_* (device pointer: the caller's, or rects_buf), consumed by it
+    DevBuf rects_buf; const int4 *rects_pending = nullptr; int rects_F = 0, rects_M = 0;
     DevBuf lab_clk;                   // LPF_LAB builds (lpf_lab_role_clock): 6 roles x 5 counters, or empty
     int geometry = 0;                 // LPF_LAB builds (lpf_set_geometry): 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes, 4 small + narrow tail
 
@@ -254,6 +256,7 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     Y.npack = 0;
     if (ride) {
         J.masks = (const uint8_t *)c->ride.masks; J.label = c->ride.label; J.M = c->ride.M; J.hw = (long long)c->H * c->W;
+        J.rects = c->ride.rects; J.W = c->W;
         J.total16 = (long long)c->ride.F * (J.hw / 16);
         Y.npack = (int)((J.total16 + LPF_BLOCK - 1) / LPF_BLOCK);
     }
@@ -565,7 +568,8 @@ int set_boxes_impl(lpf_ctx *c, const double *corners, int on_device, const int32
 
 // masks -> label image with element type LT, on stream ms, into S.label_a (S.label_b = erosion ping-pong)
 template <typename T, typename LT>
-int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks, int F, int M, int mode, int erode_iters, void **result)
+int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks, int F, int M, int mode, int erode_iters, void **result,
+               const int4 *rects = nullptr)
 {
     const size_t hw = (size_t)c->H * c->W;
     dim3 grid((c->W + LPF_TW - 1) / LPF_TW, (c->H + LPF_TH - 1) / LPF_TH, F);
@@ -580,13 +584,13 @@ int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks
             const long long total16 = (long long)F * (long long)(hw / 16);
             const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
             if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (sizeof(T) == 1 && erode_iters == 0) ? rects : (const int4 *)nullptr, c->W);
             else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (const int4 *)nullptr, c->W);
             else if (mode == 2)
-                hipLaunchKernelGGL((lpf_pack16<T, 2, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 2, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (const int4 *)nullptr, c->W);
             else
-                hipLaunchKernelGGL((lpf_pack16<T, 3, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16);
+                hipLaunchKernelGGL((lpf_pack16<T, 3, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (const int4 *)nullptr, c->W);
         } else {
             const int fuse = erode_iters > 0 ? 1 : 0;
             left -= fuse;
@@ -646,11 +650,14 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
         d_masks = (const T *)c->mask_stage.p;
     }
     const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
+    // rectangles given for these masks (lpf_set_mask_rects): used where uint8 masks are packed as they are; consumed either way
+    const int4 *rects = (sizeof(T) == 1 && mode == 0 && erode_iters == 0 && c->rects_F == F && c->rects_M == M) ? c->rects_pending : nullptr;
+    c->rects_pending = nullptr;
     c->ride.valid = false;
     if (c->fused && per_set && M > 0 && erode_iters == 0 && on_device == 2) {
         // software-pipelined modes, lent masks: left to the next lpf_run* (see lpf_ctx::Ride)
         c->ride.valid = true; c->ride.masks = d_masks; c->ride.F = F; c->ride.M = M; c->ride.label = S.label_a.p;
-        c->ride.f32 = sizeof(T) == 4; c->ride.mode = mode;
+        c->ride.f32 = sizeof(T) == 4; c->ride.mode = mode; c->ride.rects = rects;
         c->ride.can_ride = c->defer && sizeof(T) == 1 && hw % 16 == 0 && ((uintptr_t)d_masks & 15) == 0;
         S.label_bytes = lb;
         S.label_cur = S.label_a.p;
@@ -660,16 +667,16 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     if (M > 0 && erode_iters == 0 && !c->fused && on_device != 1) {
         // serial mode, nothing to erode, and the masks stay where they are (our staging buffer, or lent by the caller):
         // packing is left to the run -- a small launch does without it
-        c->lazy.valid = true; c->lazy.p = d_masks; c->lazy.f32 = sizeof(T) == 4; c->lazy.mode = mode;
+        c->lazy.valid = true; c->lazy.p = d_masks; c->lazy.f32 = sizeof(T) == 4; c->lazy.mode = mode; c->lazy.rects = rects;
         S.label_bytes = lb;
         if (!on_device) LPF_HIP(c, host_wait(c));
         c->mask_F = F; c->mask_M = M;
         return LPF_OK;
     }
     void *cur = nullptr;
-    if (lb == 1) rc = pack_typed<T, uint8_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
-    else if (lb == 2) rc = pack_typed<T, uint16_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
-    else rc = pack_typed<T, uint32_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur);
+    if (lb == 1) rc = pack_typed<T, uint8_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur, rects);
+    else if (lb == 2) rc = pack_typed<T, uint16_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur, rects);
+    else rc = pack_typed<T, uint32_t>(c, S, ms, d_masks, F, M, mode, erode_iters, &cur, rects);
     if (rc) return rc;
     S.label_bytes = lb;
     if (!on_device) LPF_HIP(c, host_wait(c));   // the host buffer may be reused by the caller
@@ -679,7 +686,7 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
 }
 
 // masks [F][M][H][W] (uint8 under rule 0, or float under rule mode) -> label image of scratch set S, by a launch of their own
-int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32, int mode, int F, int M)
+int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32, int mode, int F, int M, const int4 *rects)
 {
     const int lb = S.label_bytes;
     void *cur = nullptr;
@@ -691,9 +698,9 @@ int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32,
         else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
     } else {
         const uint8_t *m = (const uint8_t *)masks;
-        if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
-        else if (lb == 2) rc = pack_typed<uint8_t, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
-        else rc = pack_typed<uint8_t, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
+        else if (lb == 2) rc = pack_typed<uint8_t, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
+        else rc = pack_typed<uint8_t, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
     }
     if (rc) return rc;
     S.label_cur = cur;
@@ -704,7 +711,7 @@ int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32,
 int pack_ride_now(lpf_ctx *c)
 {
     if (!c->ride.valid) return LPF_OK;
-    int rc = pack_masks_now(c, c->sc[c->mask_set], c->ride.masks, c->ride.f32, c->ride.mode, c->ride.F, c->ride.M);
+    int rc = pack_masks_now(c, c->sc[c->mask_set], c->ride.masks, c->ride.f32, c->ride.mode, c->ride.F, c->ride.M, c->ride.rects);
     if (rc) return rc;
     c->ride.valid = false;
     return LPF_OK;
@@ -714,7 +721,7 @@ int pack_ride_now(lpf_ctx *c)
 int ensure_packed(lpf_ctx *c)
 {
     if (!c->lazy.valid) return LPF_OK;
-    int rc = pack_masks_now(c, c->sc[0], c->lazy.p, c->lazy.f32, c->lazy.mode, c->mask_F, c->mask_M);
+    int rc = pack_masks_now(c, c->sc[0], c->lazy.p, c->lazy.f32, c->lazy.mode, c->mask_F, c->mask_M, c->lazy.rects);
     if (rc) return rc;
     c->lazy.valid = false;
     return LPF_OK;
@@ -761,7 +768,7 @@ void lpf_destroy(lpf_ctx *c)
         DevBuf *bb[] = {&B.boxp, &B.boxq, &B.cand, &B.corners, &B.enabled, &B.aux, &B.bframes, &B.stage};
         for (DevBuf *b : bb) release(*b);
     }
-    DevBuf *all[] = {&c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->rects_buf, &c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -869,6 +876,33 @@ int lpf_lab_role_clock(lpf_ctx *c, unsigned long long *out, int reset)
     return LPF_OK;
 }
 #endif
+
+// Rectangles for the masks of the NEXT lpf_set_masks_* call: rects[F][M] = {x0, y0, x1, y1}, half open, pixels; the caller's
+// word that mask m of frame f is zero outside its rectangle (a detector's masks are cropped to their boxes).  A hint: where uint8
+// masks are packed as they are (no erosion) the pack skips the 16-pixel groups that lie outside; every other form reads the masks in
+// full.  Results are those without the hint as long as the caller's word holds.  on_device: 0 host memory (copied now, no wait),
+// else device memory read when the masks are packed (it must stay unchanged until then, like lent masks).  NULL clears.
+int lpf_set_mask_rects(lpf_ctx *c, const int32_t *rects, int on_device, int F, int M)
+{
+    if (!c) return LPF_ERR_ARG;
+    c->rects_pending = nullptr; c->rects_F = 0; c->rects_M = 0;
+    if (!rects || F <= 0 || M <= 0) return LPF_OK;
+    if (M > LPF_MAX_MASKS) return fail(c, LPF_ERR_ARG, "lpf_set_mask_rects: M=%d (at most %d)", M, LPF_MAX_MASKS);
+    if (use_device(c)) return LPF_ERR_HIP;
+    const size_t bytes = (size_t)F * M * sizeof(int4);
+    if (on_device) {
+        if (((uintptr_t)rects & 15) != 0) return fail(c, LPF_ERR_ARG, "lpf_set_mask_rects: the device array must be 16-byte aligned");
+        c->rects_pending = (const int4 *)rects;
+    } else {
+        if (c->capturing) return LPF_OK;                    // (a copy from host memory is not captured: the hint is dropped)
+        int rc = reserve(c, c->rects_buf, bytes);
+        if (rc) return rc;
+        if ((rc = upload(c, c->rects_buf.p, rects, bytes))) return rc;      // stream-ordered behind every launch that read the buffer
+        c->rects_pending = (const int4 *)c->rects_buf.p;
+    }
+    c->rects_F = F; c->rects_M = M;
+    return LPF_OK;
+}
 
 int lpf_set_pipelined(lpf_ctx *c, int on)
 {

@@ -1413,11 +1413,13 @@ struct LpfPackJob {              // uint8 masks [F][M][H][W] -> label image [F][
     const uint8_t *masks;
     void *label;
     long long hw, total16;
-    int M;
+    int M, W;
+    const int4 *rects;           // [F][M] {x0, y0, x1, y1} (half open): the caller's word that mask m of frame f is zero outside, or null
 };
 template <typename T, int MODE, typename LT>
 __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
-                                                 const int M, const long long hw, const long long total16, const long long blk);
+                                                 const int M, const long long hw, const long long total16, const long long blk,
+                                                 const int4 *__restrict__ rects, const int W);
 
 template <int ROWS, unsigned FL, typename LT, bool PRE, bool BOXES>
 __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y,
@@ -1457,7 +1459,7 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         const int r = b - periodic;
         if (r >= Y.rest) {                                  // ---- the mask pack (mode 4): behind the tiles, it fills their ramp-down
             if constexpr (!LpfIsDirect<LT>::value) {        // (tiles that read the masks directly never share a launch with a pack)
-                if (r - Y.rest < Y.npack) { lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest); LPF_ROLE_END(4) }
+                if (r - Y.rest < Y.npack) { lpf_pack16_block<uint8_t, 0, LT>(J.masks, static_cast<LT *>(J.label), J.M, J.hw, J.total16, r - Y.rest, J.rects, J.W); LPF_ROLE_END(4) }
             }
             return;
         }
@@ -1840,9 +1842,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_job_kernel(const LpfBoxJob 
 // Streaming pack, 16 pixels per lane: uint8 masks are read 16 bytes per lane per mask
 // (float masks 4 x 16 bytes), the packed labels leave as four 16-byte stores.
 // Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).
+// Mask rectangles (lpf_set_mask_rects): a detector hands out every mask with its 2D box and the mask is zero outside it
+// (ultralytics crops the masks to their boxes) -- a real frame's five masks are 2.6 MB of which a few per cent lie inside the boxes.
+// With the rectangles the pack reads a group of 16 pixels of mask m only where it meets m's rectangle; the label image is written
+// in full either way.  uint8 masks under rule 0 only (the other forms ignore the hint).
 template <typename T, int MODE, typename LT>
 __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
-                                                 const int M, const long long hw, const long long total16, const long long blk)
+                                                 const int M, const long long hw, const long long total16, const long long blk,
+                                                 const int4 *__restrict__ rects, const int W)
 {
     const long long g = blk * LPF_BLOCK + threadIdx.x;      // group of 16 pixels, over all frames
     if (g >= total16) return;
@@ -1853,10 +1860,20 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
 #pragma unroll
     for (int i = 0; i < 16; ++i) bits[i] = 0;
     if (sizeof(T) == 1) {
+        const int y = rects ? (int)(o / W) : 0, x = rects ? (int)(o - (long long)y * W) : 0;       // the group's first pixel
+        const bool whole = !rects || x + 16 > W;            // (a group that runs over the end of a row is read whatever the rectangles say)
         for (int m0 = 0; m0 < M; m0 += 8) {                 // eight independent 16-byte loads in flight
             uint4 q[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const uint4 *>(mf + (size_t)min(m0 + j, M - 1) * hw);
+            for (int j = 0; j < 8; ++j) {
+                const int m = min(m0 + j, M - 1);
+                bool hit = whole;
+                if (!whole) {
+                    const int4 r = rects[(size_t)f * M + m];
+                    hit = y >= r.y && y < r.w && x + 16 > r.x && x < r.z;
+                }
+                q[j] = hit ? *reinterpret_cast<const uint4 *>(mf + (size_t)m * hw) : make_uint4(0u, 0u, 0u, 0u);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (m0 + j < M) {
@@ -1911,9 +1928,9 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
 
 template <typename T, int MODE, typename LT>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ masks, LT *__restrict__ label,
-                                                        int M, long long hw, long long total16)
+                                                        int M, long long hw, long long total16, const int4 *__restrict__ rects, int W)
 {
-    lpf_pack16_block<T, MODE, LT>(masks, label, M, hw, total16, (long long)blockIdx.x);
+    lpf_pack16_block<T, MODE, LT>(masks, label, M, hw, total16, (long long)blockIdx.x, rects, W);
 }
 
 // General-shape pack with optional fused first erosion: 64x16 output tile per block,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """146 real frames per step (the four full-size golden frames in turn, ~16.9 M points): in-order steps for a kernel trace.
-usage: rocprofv3 --kernel-trace --stats ... -- python3 tools/real_probe.py [serial|fused|fused-pack] [noboxes|nolists|nomasks|-] [frames] [geometry: lab build]"""
+usage: rocprofv3 --kernel-trace --stats ... -- python3 tools/real_probe.py [serial|fused|fused-pack] [noboxes|nolists|nomasks|rects|-] [frames] [geometry: lab build]"""
 import os
 import sys
 import time
@@ -48,7 +48,8 @@ with LpfContext(0, library=_build.LAB_LIB if geometry else None) as ctx:
         ctx.set_geometry(geometry)
     ctx.set_pipelined(False if mode == "serial" else mode)
     ctx.set_camera(T, K, W, H, 0.0, 50.0)
-    fn = ctx.make_device_step(d_pts, off, masks_u8=None if lab == "nomasks" else d_masks, lend=True, boxes_cam0=None if lab == "noboxes" else d_cam0,
+    d_rects = torch.from_numpy(LpfContext.mask_rects(np.stack([f["masks"] for f in batch]))).to(dev) if lab == "rects" else None     # the masks' 2D rectangles (lpf_set_mask_rects)
+    fn = ctx.make_device_step(d_pts, off, masks_u8=None if lab == "nomasks" else d_masks, lend=True, boxes_cam0=None if lab == "noboxes" else d_cam0, mask_rects=d_rects,
                               box_off=boff, T_cam_to_velo=Tcv, inst_cap=cap, **o)
     for _ in range(5):
         fn()
