@@ -1864,19 +1864,22 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
         const bool whole = !rects || x + 16 > W;            // (a group that runs over the end of a row is read whatever the rectangles say)
         for (int m0 = 0; m0 < M; m0 += 8) {                 // eight independent 16-byte loads in flight
             uint4 q[8];
+            unsigned hm = 0xFFu;                            // masks of this round whose rectangle the group meets
+            if (!whole) {
+                hm = 0u;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = min(m0 + j, M - 1);
-                bool hit = whole;
-                if (!whole) {
-                    const int4 r = rects[(size_t)f * M + m];
-                    hit = y >= r.y && y < r.w && x + 16 > r.x && x < r.z;
+                for (int j = 0; j < 8; ++j) {
+                    const int4 r = rects[(size_t)f * M + min(m0 + j, M - 1)];
+                    if (y >= r.y && y < r.w && x + 16 > r.x && x < r.z) hm |= 1u << j;
                 }
-                q[j] = hit ? *reinterpret_cast<const uint4 *>(mf + (size_t)m * hw) : make_uint4(0u, 0u, 0u, 0u);
+                if (hm == 0u) continue;                     // (most groups of a real frame: nothing to read, nothing to extract)
             }
 #pragma unroll
+            for (int j = 0; j < 8; ++j)
+                q[j] = ((hm >> j) & 1u) ? *reinterpret_cast<const uint4 *>(mf + (size_t)min(m0 + j, M - 1) * hw) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (m0 + j < M) {
+                if (m0 + j < M && ((hm >> j) & 1u)) {
                     const unsigned wv[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
                     for (int i = 0; i < 16; ++i)

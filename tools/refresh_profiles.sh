@@ -47,6 +47,10 @@ for M in serial fused-pack; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_$M" -- python3 "$R/tools/real_probe.py" $M > "$O/real_$M.txt" 2> /dev/null
   cp "$(ls -t "$O"/ktrace_real_$M/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_$M.csv"; cat "$O/real_$M.txt"
 done
+echo "[2d] the same with the masks' 2D rectangles (lpf_set_mask_rects), in order"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_rects" -- python3 "$R/tools/real_probe.py" serial rects > "$O/real_rects.txt" 2> /dev/null
+cp "$(ls -t "$O"/ktrace_real_rects/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_serial_mask_rects.csv"; cat "$O/real_rects.txt"
+timeout -k 10 200 python3 "$R/tools/real_probe.py" fused-pack rects 2> /dev/null
 pmc
 lines
 [ "$WHAT" = quick ] && exit 0
