@@ -41,7 +41,7 @@ extern "C" {
                                          geometry tables per run (a new batch shape no longer drains the pipeline);
                                          lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
                                          section 8); lpf_set_geometry only in lab builds (-DLPF_LAB)
-                                      6: lpf_set_mask_rects (added; nothing else changed) */
+                                      6: lpf_set_mask_rects, lpf_resize_masks_u8 (added; nothing else changed) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -244,6 +244,15 @@ int lpf_points_in_boxes(lpf_ctx *ctx, const float *pts, int64_t k, int stride, c
  * (0 where no valid point projects), winner: int32 [H][W] index of that point or -1 (may be NULL).
  * Uses lpf_set_camera's transform and depth window.  pts as in lpf_run; outputs follow on_device. */
 int lpf_depth_image(lpf_ctx *ctx, const float *pts, int64_t N, int on_device, double *depth_img, int32_t *winner);
+
+/* cv2.resize(mask.astype(np.uint8), (camera.width, camera.height)) (V3:222; INTER_LINEAR, the default) for masks that do not arrive at
+ * the camera's size (the reference's scripts all pass retina_masks=True, so theirs do): n planes [h][w] of uint8 -> n planes [H][W]
+ * (the size of lpf_set_camera), which then go to lpf_set_masks_u8 (nonzero = member = the reference's `> 0.5`).  Restated from
+ * OpenCV 4.x resize.cpp (HResizeLinear / VResizeLinear, 11-bit weights) and pinned by construction only -- OpenCV is not part of this
+ * image and the reference holds no resized fixture (oracle/numpy_path.py: cv2_resize_linear_u8 states the formula).  An exact 2 x 2
+ * decimation, which OpenCV hands to INTER_AREA, is refused.  on_device: both pointers in host (0) or device (1) memory; device
+ * callers: in stream order.  Not capturable. */
+int lpf_resize_masks_u8(lpf_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst, int on_device);
 
 /* ---- box preparation on the GPU --------------------------------------------------------------
  * For nbox annotated boxes given by their 8 corners in the cam-0 frame (f64 [nbox][8][3], the

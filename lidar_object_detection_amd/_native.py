@@ -90,6 +90,7 @@ def load(path=None):
     lib.lpf_set_camera.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_mask_rects.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.lpf_resize_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_label_image.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_get_label_image.argtypes = [_P, _P, ctypes.c_int]
@@ -125,7 +126,7 @@ EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "l
             "lpf_set_pipelined", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_mask_rects", "lpf_set_label_image",
             "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_resize_masks_u8", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
             "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
 
@@ -394,6 +395,28 @@ class LpfContext:
         self.W, self.H = int(width), int(height)
 
     BINARIZE = {"astype": 0, "v3": 1, "gt0.5": 2}
+
+    def resize_masks(self, masks):
+        """cv2.resize(mask.astype(np.uint8), (W, H)) (V3:222, INTER_LINEAR) for masks [..., h, w] that are not at the camera's size:
+        returns uint8 [..., H, W] -- a NumPy array for a NumPy / list input, a torch GPU tensor for a uint8 torch GPU tensor (in stream
+        order).  Float masks are cast first, as the reference casts them (``astype(np.uint8)``: truncation).  Restated from OpenCV's
+        C++ reference path, pinned by construction only (oracle/numpy_path.py: cv2_resize_linear_u8)."""
+        if _is_torch(masks):
+            import torch
+            if str(masks.dtype) != "torch.uint8" or not masks.is_contiguous():
+                masks = masks.to(torch.uint8).contiguous()       # (torch's float -> uint8 cast truncates, as astype does for 0 <= v < 256)
+            shape = tuple(masks.shape)
+            out = torch.empty(shape[:-2] + (self.H, self.W), dtype=torch.uint8, device=masks.device)
+            n = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+            self._check(self._lib.lpf_resize_masks_u8(self._h, _dev_ptr(masks) if n else None, n, shape[-2], shape[-1], _dev_ptr(out) if n else None, 1))
+            return out
+        a = np.asarray(masks)
+        a = np.ascontiguousarray(a.astype(np.uint8))
+        shape = a.shape
+        out = np.empty(shape[:-2] + (self.H, self.W), np.uint8)
+        n = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+        self._check(self._lib.lpf_resize_masks_u8(self._h, a.ctypes.data if n else None, n, shape[-2], shape[-1], out.ctypes.data if n else None, 0))
+        return out
 
     def set_mask_rects(self, rects):
         """Hint for the NEXT set_masks call: rects int32 [M,4] or [F,M,4] = (x0, y0, x1, y1), half open, pixels -- mask m of frame f is

@@ -138,6 +138,7 @@ struct lpf_ctx {
     // launches, [4] box jobs launched as a kernel of their own, [5] box jobs that rode in a step launch, [6] blocking uploads
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // lpf_set_mask_rects: rectangles for the NEXT lpf_set_masks_* (device pointer: the caller's, or rects_buf), consumed by it
+    DevBuf resize_buf;                // lpf_resize_masks_u8: weight tables (+ staging for host callers)
     DevBuf rects_buf; const int4 *rects_pending = nullptr; int rects_F = 0, rects_M = 0;
     DevBuf lab_clk;                   // LPF_LAB builds (lpf_lab_role_clock): 6 roles x 5 counters, or empty
     int geometry = 0;                 // LPF_LAB builds (lpf_set_geometry): 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes, 4 small + narrow tail
@@ -768,7 +769,7 @@ void lpf_destroy(lpf_ctx *c)
         DevBuf *bb[] = {&B.boxp, &B.boxq, &B.cand, &B.corners, &B.enabled, &B.aux, &B.bframes, &B.stage};
         for (DevBuf *b : bb) release(*b);
     }
-    DevBuf *all[] = {&c->rects_buf, &c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->resize_buf, &c->rects_buf, &c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -1384,6 +1385,76 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
     LPF_HIP(c, hipGetLastError());
     if (!on_device) LPF_HIP(c, hipMemcpyAsync(inside, d_out, (size_t)k * B, hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, host_wait(c));           // bp is a local
+    return LPF_OK;
+}
+
+// OpenCV's weight table of one axis (resize.cpp: the xofs / alpha loop of resizeGeneric_, 8-bit INTER_LINEAR): per destination index
+// {source index, second source index, w0, w1}.  Every step is a separate IEEE operation (volatile: no contraction, no excess precision).
+static void resize_table(int n_dst, int n_src, std::vector<int4> &tab)
+{
+    tab.resize((size_t)n_dst);
+    volatile double ratio = (double)n_dst / (double)n_src;
+    volatile double scale = 1.0 / ratio;
+    for (int d = 0; d < n_dst; ++d) {
+        volatile double a = ((double)d + 0.5) * scale;
+        volatile double b = a - 0.5;
+        volatile float f = (float)b;
+        int s = (int)floorf(f);
+        volatile float fr = f - (float)s;
+        if (s < 0) { s = 0; fr = 0.f; }
+        if (s >= n_src - 1) { s = n_src - 1; fr = 0.f; }
+        volatile float one_minus = 1.0f - fr;
+        volatile float p0 = one_minus * 2048.0f, p1 = fr * 2048.0f;
+        long w0 = lrintf(p0), w1 = lrintf(p1);              // round half to even (the default rounding mode), as cvRound
+        w0 = w0 < -32768 ? -32768 : w0 > 32767 ? 32767 : w0;
+        w1 = w1 < -32768 ? -32768 : w1 > 32767 ? 32767 : w1;
+        tab[(size_t)d] = make_int4(s, s + 1 < n_src ? s + 1 : n_src - 1, (int)w0, (int)w1);
+    }
+}
+
+// n planes [h][w] of uint8 -> n planes at the camera's size [H][W], as cv2.resize(plane, (W, H)) does (INTER_LINEAR; V3:222).
+int lpf_resize_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, uint8_t *dst, int on_device)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera has not been called (the target size is the camera's)");
+    if (n < 0 || h <= 0 || w <= 0 || (n > 0 && (!src || !dst)) || (long long)n * h * w > (1ll << 40))
+        return fail(c, LPF_ERR_ARG, "resize_masks: n=%d h=%d w=%d src=%p dst=%p", n, h, w, (const void *)src, (void *)dst);
+    if (n == 0) return LPF_OK;
+    const int W = c->W, H = c->H;
+    if (w == 2 * W && h == 2 * H)
+        return fail(c, LPF_ERR_ARG, "resize_masks: cv2.resize hands an exact 2 x 2 decimation to INTER_AREA, which is not restated here");
+    const size_t in_bytes = (size_t)n * h * w, out_bytes = (size_t)n * H * W;
+    int rc;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "resize_masks inside a graph capture");
+    if (anything_owed(c) && (rc = sync_all(c))) return rc;                // (the staging buffers below may be in use by owed runs)
+    const uint8_t *dS = src;
+    uint8_t *dD = dst;
+    std::vector<int4> xt, yt;
+    resize_table(W, w, xt);
+    resize_table(H, h, yt);
+    const size_t tab_bytes = ((size_t)W + (size_t)H) * sizeof(int4);
+    if ((rc = reserve(c, c->resize_buf, tab_bytes + (on_device ? 0 : in_bytes + out_bytes)))) return rc;
+    LPF_HIP(c, hipMemcpyAsync(c->resize_buf.p, xt.data(), (size_t)W * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    LPF_HIP(c, hipMemcpyAsync((char *)c->resize_buf.p + (size_t)W * sizeof(int4), yt.data(), (size_t)H * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    if (!on_device) {
+        dS = (const uint8_t *)c->resize_buf.p + tab_bytes;
+        dD = (uint8_t *)c->resize_buf.p + tab_bytes + in_bytes;
+        LPF_HIP(c, hipMemcpyAsync((void *)dS, src, in_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    LPF_HIP(c, host_wait(c));                              // (the tables are host vectors of this call)
+    if ((h == H && w == W)) {
+        LPF_HIP(c, hipMemcpyAsync(dD, dS, out_bytes, hipMemcpyDeviceToDevice, c->stream));       // cv2.resize to the same size copies
+    } else {
+        const long long total = (long long)out_bytes;
+        hipLaunchKernelGGL(lpf_resize_linear_u8_kernel, dim3((unsigned)((total + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,
+                           dS, dD, (const int4 *)c->resize_buf.p, (const int4 *)c->resize_buf.p + W, w, h, W, H, total);
+        LPF_HIP(c, hipGetLastError());
+    }
+    if (!on_device) {
+        LPF_HIP(c, hipMemcpyAsync(dst, dD, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        LPF_HIP(c, host_wait(c));
+    }
     return LPF_OK;
 }
 

@@ -1473,6 +1473,30 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
 }
 
 // ------------------------------------------------------------------------------------
+// cv2.resize(mask_u8, (W, H)), INTER_LINEAR on 8-bit data (V3:222 for masks that do not arrive at camera size), as OpenCV 4.x's
+// C++ reference path computes it (resize.cpp: HResizeLinear / VResizeLinear, 11-bit weights; restated and cited in
+// oracle/numpy_path.py: cv2_resize_linear_u8 -- pinned by construction only, OpenCV is not in the image).  The weight tables
+// {source index, second index, w0, w1} per destination column and row are made on the host as OpenCV makes them; a thread
+// produces one destination pixel: two 32-bit horizontal sums, then the vertical fixed-point blend.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_resize_linear_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                                         const int4 *__restrict__ xtab, const int4 *__restrict__ ytab,
+                                                                         const int w, const int h, const int W, const int H, const long long total)
+{
+    const long long i = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    const long long hw = (long long)W * H;
+    const long long n = i / hw;
+    const int rem = (int)(i - n * hw), y = rem / W, x = rem - y * W;
+    const int4 cx = xtab[x], cy = ytab[y];
+    const uint8_t *__restrict__ s = src + (size_t)n * w * h;
+    const int r0 = cy.x * w, r1 = cy.y * w;
+    const int S0 = (int)s[r0 + cx.x] * cx.z + (int)s[r0 + cx.y] * cx.w;
+    const int S1 = (int)s[r1 + cx.x] * cx.z + (int)s[r1 + cx.y] * cx.w;
+    dst[i] = (uint8_t)((((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ------------------------------------------------------------------------------------
 // Standalone K6: inside[b][i] for k points x B boxes -- the drop-in for
 // oriented_point_in_bbox / point_in_bbox (V3:143-208), which return the per-point mask.
 // Box parameters are staged in LDS 32 boxes at a time; one thread per point.

@@ -46,14 +46,22 @@ def _is_device_tensor(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
-def _mask_stack(masks, camera):
-    """[M,H,W] float32/uint8 array from the reference's mask list; identity resize only.  A torch tensor that is
-    already on the GPU -- ``result.masks.data`` before the reference's ``.cpu().numpy()`` (V3:72) -- is passed through:
-    the kernels read it where it is."""
+def _mask_stack(masks, camera, resize_ctx=None):
+    """[M,H,W] float32/uint8 array from the reference's mask list.  A torch tensor that is already on the GPU --
+    ``result.masks.data`` before the reference's ``.cpu().numpy()`` (V3:72) -- is passed through: the kernels read it where it is.
+    Masks that do not arrive at the camera's size (the reference's scripts pass retina_masks=True, V3:64, so theirs do) go through
+    ``cv2.resize(mask.astype(np.uint8), (W, H))`` as V3:222 does it -- on the GPU, by ``resize_ctx`` (whose camera must have been
+    set; LpfContext.resize_masks) -- and come back as uint8 [M,H,W], nonzero = the reference's ``> 0.5``."""
+    def resized(m):
+        if resize_ctx is None:
+            raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64) in this call" % (camera.height, camera.width))
+        return resize_ctx.resize_masks(m)
     if _is_device_tensor(masks):
         import torch
-        if masks.ndim != 3 or tuple(masks.shape[1:]) != (camera.height, camera.width):
-            raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64)" % (camera.height, camera.width))
+        if masks.ndim != 3:
+            raise ValueError("device masks must be [M,h,w]")
+        if tuple(masks.shape[1:]) != (camera.height, camera.width):
+            return resized(masks)
         if masks.dtype == torch.bool:
             masks = masks.to(torch.uint8)
         elif masks.dtype not in (torch.float32, torch.uint8):
@@ -62,9 +70,10 @@ def _mask_stack(masks, camera):
     m = np.asarray(masks)
     if m.size == 0:
         return np.zeros((0, camera.height, camera.width), np.uint8)
-    if m.ndim != 3 or m.shape[1:] != (camera.height, camera.width):
-        raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64); cv2.resize to another "
-                                  "size is not part of this path" % (camera.height, camera.width))
+    if m.ndim != 3:
+        raise ValueError("masks must be [M,h,w]")
+    if m.shape[1:] != (camera.height, camera.width):
+        return resized(m)
     if m.dtype.kind == "f":
         return np.ascontiguousarray(m, dtype=np.float32)
     return np.ascontiguousarray(m.astype(np.uint8))
@@ -166,17 +175,17 @@ def extract_car_points_by_mask(points_valid, u_valid, v_valid, masks, camera, de
     (run on the already-projected pixels with an identity camera)."""
     pv = np.asarray(points_valid)
     n = pv.shape[0]
-    stack = _mask_stack(masks, camera)
+    ctx = get_context(device)
+    ctx.set_camera(np.eye(4), np.eye(3), camera.width, camera.height, 0.0, 2.0)
+    stack = _mask_stack(masks, camera, resize_ctx=ctx)       # (V3:222: masks of another size are resized, on the GPU)
     M = stack.shape[0]
     sets = []
     if M == 0:
         return sets
-    ctx = get_context(device)
     pix = np.zeros((n, 4), np.float32)
     pix[:, 0] = np.asarray(u_valid)
     pix[:, 1] = np.asarray(v_valid)
     pix[:, 2] = 1.0
-    ctx.set_camera(np.eye(4), np.eye(3), camera.width, camera.height, 0.0, 2.0)
     ctx.clear_boxes()
     for m0 in range(0, M, LPF_MAX_MASKS):
         ctx.set_masks(stack[m0:m0 + LPF_MAX_MASKS])
@@ -701,7 +710,10 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         return []
     ctx = ctx or get_context(device)
     H, W = camera.height, camera.width
-    stacks = [_mask_stack(f.masks if f.masks is not None else [], camera) for f in frames]
+    ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
+    # (masks of another size than the camera's: cv2.resize as V3:222, on the GPU -- not with the V3 erosion block, which erodes at the
+    #  masks' own size before the resize)
+    stacks = [_mask_stack(f.masks if f.masks is not None else [], camera, resize_ctx=None if (erode_iters or v3_pipeline) else ctx) for f in frames]
     M = max(s.shape[0] for s in stacks)
     if M > LPF_MAX_MASKS:
         # The reference loops over every mask (V3:220), with no bound; a launch labels a point with one bit per mask in a
@@ -730,7 +742,6 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         c, pos = _corners_velo(f.bboxes_3d)
         corners.append(c)
         positions.append(pos)
-    ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
     ctx.set_masks(batch, erode_iters=erode_iters, v3_pipeline=v3_pipeline, lend=True)   # (the run follows in this call: GPU masks can be lent)
     ctx.set_boxes(corners, oriented=use_oriented)
     # only the valid points' pixels and labels are used below: fetch those (a quarter of the dense arrays on real frames)

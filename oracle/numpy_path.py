@@ -84,3 +84,47 @@ def prepare_boxes(corners_cam0, K3, W, H, TrVeloToCam):
         corners_h = np.hstack([corners, np.ones((8, 1))])
         velo[b] = (TrCamToVelo @ corners_h.T).T[:, :3]
     return visible, velo
+
+
+def cv2_resize_linear_u8(src, W, H):
+    """``cv2.resize(src_u8, (W, H))`` with the default INTER_LINEAR on 8-bit data (V3:222: ``cv2.resize(mask.astype(np.uint8),
+    (camera.width, camera.height))``), restated.  THIRD-PARTY ALGORITHM, PINNED BY CONSTRUCTION ONLY: OpenCV is not installed in this
+    image and the reference holds no fixture of a resized mask; this follows OpenCV 4.x ``modules/imgproc/src/resize.cpp`` --
+    ``resizeGeneric_`` with ``HResizeLinear<uchar, int, short, 2048>`` and ``VResizeLinear<uchar, int, short,
+    FixedPtCast<int, uchar, 22>>`` (INTER_RESIZE_COEF_BITS = 11) -- as its C++ reference path computes it:
+      * per destination column dx: ``fx = float((dx + 0.5) * scale_x - 0.5)`` with ``scale_x = 1 / (double(W) / w)``;
+        ``sx = floor(fx)``, ``fx -= sx``; ``sx < 0 -> sx = 0, fx = 0``; ``sx >= w - 1 -> sx = w - 1, fx = 0``;
+        weights ``a0 = saturate_short(round_half_even((1 - fx) * 2048))``, ``a1 = saturate_short(round_half_even(fx * 2048))``;
+        the same per row with fy, b0, b1;
+      * horizontal pass, 32-bit: ``S = src[sx] * a0 + src[min(sx + 1, w - 1)] * a1`` (beyond the last source column: src[sx] * 2048);
+      * vertical pass: ``dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2``.
+    Not restated: the exact 2 x 2 decimation case, which OpenCV hands to INTER_AREA (raises NotImplementedError), and whatever a
+    SIMD / IPP build of OpenCV rounds differently.  Equal sizes return the input (cv2.resize copies)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    if (h, w) == (H, W):
+        return src.copy()
+    if w == 2 * W and h == 2 * H:
+        raise NotImplementedError("cv2.resize hands an exact 2 x 2 decimation to INTER_AREA")
+
+    def coeffs(n_dst, n_src):
+        scale = 1.0 / (float(n_dst) / float(n_src))                       # double, as resize() computes it
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo] = 0; f[lo] = 0.0
+        hi = s >= n_src - 1
+        s[hi] = n_src - 1; f[hi] = 0.0
+        c0 = np.clip(np.rint((np.float32(1.0) - f) * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+        c1 = np.clip(np.rint(f * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+        return s, np.minimum(s + 1, n_src - 1), c0, c1
+
+    sx, sx1, a0, a1 = coeffs(W, w)
+    sy, sy1, b0, b1 = coeffs(H, h)
+    s = src.astype(np.int64)
+    rows = s[:, sx] * a0[None, :] + s[:, sx1] * a1[None, :]                  # [h, W] 32-bit sums (<= 255 * 2048)
+    S0, S1 = rows[sy], rows[sy1]                                             # [H, W]
+    out = (((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)

@@ -1,0 +1,83 @@
+"""cv2.resize(mask.astype(np.uint8), (W, H)) for masks that do not arrive at the camera's size (V3:222).  OpenCV is not installed
+here and the reference holds no resized fixture: the restatement (oracle/numpy_path.py: cv2_resize_linear_u8, from OpenCV 4.x
+resize.cpp) is PINNED BY CONSTRUCTION ONLY -- against values derived by hand from its formula and against two small results that
+OpenCV's documentation and countless bug reports quote -- and the HIP kernel is compared with it bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import numpy_path as npp
+
+
+def test_restatement_on_hand_derived_values():
+    # [0, 255] -> 4 wide: sample positions 0.25 / 0.75 between the two pixels: 63.75 -> 64, 191.25 -> 191; clamped ends
+    assert npp.cv2_resize_linear_u8(np.array([[0, 255]], np.uint8), 4, 1).tolist() == [[0, 64, 191, 255]]
+    # the 2 x 2 checker that OpenCV users post: separable, so every row / column is the line above or a blend of two
+    want = [[0, 64, 191, 255], [64, 96, 159, 191], [191, 159, 96, 64], [255, 191, 64, 0]]
+    assert npp.cv2_resize_linear_u8(np.array([[0, 255], [255, 0]], np.uint8), 4, 4).tolist() == want
+    # a 0 / 1 mask doubled: weights 0.25 / 0.75 -> 0.75 rounds to 1, 0.25 to 0: the region grows to exactly twice its size
+    m = np.zeros((4, 6), np.uint8); m[1:3, 2:5] = 1
+    out = npp.cv2_resize_linear_u8(m, 12, 8)
+    want = np.zeros((8, 12), np.uint8); want[2:6, 4:10] = 1
+    assert np.array_equal(out, want)
+    # by hand, one pixel of a 3 x 4 -> 2 x 3 reduction: dx = 1: fx = 1.5 * (4/3) - 0.5 = 1.5 -> sx = 1, weights 1024 / 1024;
+    # dy = 0: fy = 0.5 * 1.5 - 0.5 = 0.25 -> sy = 0, weights 1536 / 512
+    src = (np.arange(12, dtype=np.uint8).reshape(3, 4) * 20)
+    S0 = 20 * 1024 + 40 * 1024; S1 = 100 * 1024 + 120 * 1024
+    px = (((1536 * (S0 >> 4)) >> 16) + ((512 * (S1 >> 4)) >> 16) + 2) >> 2
+    assert npp.cv2_resize_linear_u8(src, 3, 2)[0, 1] == px == 50
+    # equal sizes: a copy; an exact 2 x 2 decimation is OpenCV's INTER_AREA case: refused
+    assert np.array_equal(npp.cv2_resize_linear_u8(src, 4, 3), src)
+    with pytest.raises(NotImplementedError):
+        npp.cv2_resize_linear_u8(np.zeros((8, 8), np.uint8), 4, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(188, 704), (104, 384), (160, 608), (376, 1408), (500, 1900), (1, 1), (3, 2000), (533, 17), (200, 1408)])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_kernel_equals_the_restatement(calib, hw, where):
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext
+    _, T, K, W, H = S.default_calibration(calib)
+    h, w = hw
+    rng = np.random.default_rng(h * 7919 + w)
+    planes = np.stack([(rng.random((h, w)) < 0.4).astype(np.uint8),                       # a 0 / 1 mask
+                       rng.integers(0, 256, (h, w)).astype(np.uint8),                     # any bytes
+                       np.full((h, w), 255, np.uint8)])
+    with LpfContext(0) as ctx:
+        ctx.set_camera(T, K, W, H, 0.0, 50.0)
+        if where == "host":
+            out = ctx.resize_masks(planes)
+        else:
+            out = ctx.resize_masks(torch.from_numpy(planes).to(torch.device("cuda", 0))).cpu().numpy()
+    assert out.shape == (3, H, W) and out.dtype == np.uint8
+    for a, p in zip(out, planes):
+        assert np.array_equal(a, npp.cv2_resize_linear_u8(p, W, H))
+
+
+@pytest.mark.gpu
+def test_masks_of_another_size_through_the_reference_shaped_calls(calib):
+    """run_frames and extract_car_points_by_mask with masks at the detector's own size == the same calls with the masks resized
+    beforehand (by the restatement); float masks are cast as the reference casts them."""
+    from lidar_object_detection_amd import pipeline
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    cam = type("Cam", (), {"K": np.asarray(K), "width": W, "height": H})()
+    sc = S.scene(120_000, n_masks=5, n_boxes=12, seed=8300, calib=calib)
+    small = np.stack([m[::2, ::2] for m in sc["masks"]]).astype(np.float32)               # [5, H/2, W/2] float 0. / 1., as a detector's
+    small[0] *= 0.9                                                                       # astype(uint8) -> 0: this mask vanishes
+    full = np.stack([npp.cv2_resize_linear_u8(m.astype(np.uint8), W, H) for m in small])
+    assert not full[0].any() and full[1].any()
+    boxes3d = [{"corners_velo": c.tolist()} for c in sc["corners_velo"]]
+    a = pipeline.run_frames([pipeline.FrameInputs(1, sc["points"], small, boxes3d, pipeline.default_colors(5))], T, cam, 50.0, 10, True)[0]
+    b = pipeline.run_frames([pipeline.FrameInputs(1, sc["points"], full, boxes3d, pipeline.default_colors(5))], T, cam, 50.0, 10, True)[0]
+    assert np.array_equal(a["count_mb"], b["count_mb"]) and np.array_equal(a["bg_assigned"], b["bg_assigned"]) and sum(len(x) for x in a["car_point_sets"]) > 100
+    for x, y in zip(a["car_point_sets"], b["car_point_sets"]):
+        assert np.array_equal(x, y)
+    sa = pipeline.extract_car_points_by_mask(a["points_valid"], a["u_valid"], a["v_valid"], small, cam)
+    sb = pipeline.extract_car_points_by_mask(a["points_valid"], a["u_valid"], a["v_valid"], full, cam)
+    assert len(sa) == 5 and sum(len(x) for x in sa) > 100
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    with pytest.raises(NotImplementedError):                                              # the V3 erosion block erodes at the masks' own size first
+        pipeline.run_frames([pipeline.FrameInputs(1, sc["points"], small, boxes3d, pipeline.default_colors(5))], T, cam, 50.0, 10, True, erode_iters=1)
