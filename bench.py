@@ -53,12 +53,11 @@ PMC_FILE = "r03_pmc_bench_f8x2M.json"
 
 
 def kernel_source_sha():
-    """sha256 (16 hex digits) of the kernel sources: a committed counter pass only describes the kernels it ran."""
-    h = hashlib.sha256()
-    for name in ("lpf_kernels.hip.h", "lpf_api.hip"):
-        with open(os.path.join(ROOT, "lidar_object_detection_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    """The id of the kernel sources (csrc/ + include/lpf.h + compiler flags, _build.source_id): what liblpf.so carries as
+    lpf_build_id().  A committed counter pass only describes the kernels it ran; a number is only printed for a library built
+    from the sources beside it."""
+    from lidar_object_detection_amd import _build
+    return _build.source_id()
 
 
 def pmc_traffic(points_per_launch, kernel="lpf_k1_project_t"):
@@ -599,6 +598,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:], dry=args.dry_launch)
+    # Which binary is measured: the package's liblpf.so, built from the sources beside it (the loader rebuilds or refuses a stale
+    # one).  LPF_LIBRARY may name another build only in a lab run, whose line is marked as such and is never a result.
+    if args.lab:
+        os.environ["LPF_LAB"] = "1"
+    elif os.environ.get("LPF_LIBRARY"):
+        raise SystemExit("bench.py: LPF_LIBRARY is set (%s) but this is not a --lab run: refusing to time another library" % os.environ["LPF_LIBRARY"])
 
     import torch
     import torch.distributed as dist
@@ -662,6 +667,8 @@ def main():
     frame_off = np.arange(F + 1, dtype=np.int64) * n
     box_off = np.arange(F + 1, dtype=np.int32) * N_BOXES
 
+    library = {}                                                       # {"path", "build_id"} of the liblpf.so the contexts loaded
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -673,6 +680,9 @@ def main():
         # of the gathers): the context gets an explicit device-side edge behind that stream before its first kernel, instead
         # of relying on a device-wide synchronisation ("The bench_s1 fault").
         ctx = LpfContext(local_rank)
+        library.update(ctx.library)
+        if not args.lab and library["build_id"] != kernel_source_sha():
+            raise SystemExit("bench.py: %s reports build id %s, the sources are %s" % (library["path"], library["build_id"], kernel_source_sha()))
         ctx.set_pipelined(MODES[mode][0])
         ctx.set_camera(T, K, W, H, 0.0, DMAX)
         if not per_step_boxes and args.lab not in ("noboxes", "nowork"):
@@ -788,7 +798,11 @@ def main():
                        "host_while_queueing_the_timed_steps": main_run["queued"],
                        "step_algorithmic_frac_of_hbm_peak": ALGO_BYTES_PER_POINT * ntot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                        "checked": main_run.get("checked"),
-                       "sharding": "clouds per rank, no data-path collective"},
+                       "sharding": "clouds per rank, no data-path collective",
+                       "library": {"path": os.path.relpath(library.get("path", "?"), ROOT), "build_id": library.get("build_id"),
+                                   "sources_id": kernel_source_sha()},
+                       "ranks": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                                 "dist_world_size": (dist.get_world_size() if world > 1 else 1)}},
         }
         if k1_n:
             dur_s = 1e-3 * k1_ms / k1_n                              # mean event bracket around the kernel

@@ -25,6 +25,7 @@
 #ifndef LPF_H
 #define LPF_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -32,7 +33,7 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 6          /* 2: lpf_outputs gained uv_valid / label_valid
+#define LPF_ABI_VERSION 7          /* 2: lpf_outputs gained uv_valid / label_valid
                                       3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
                                          lpf_set_pipelined modes; stale graphs are refused
                                       4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4)
@@ -41,7 +42,8 @@ extern "C" {
                                          geometry tables per run (a new batch shape no longer drains the pipeline);
                                          lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
                                          section 8); lpf_set_geometry only in lab builds (-DLPF_LAB)
-                                      6: lpf_set_mask_rects, lpf_resize_masks_u8 (added; nothing else changed) */
+                                      6: lpf_set_mask_rects, lpf_resize_masks_u8 (added; nothing else changed)
+                                      7: lpf_build_id, lpf_host_alloc / lpf_host_free, lpf_run_frame (added; nothing else changed) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -93,6 +95,14 @@ typedef struct lpf_outputs {
 
 /* ---- lifetime ---------------------------------------------------------------- */
 int  lpf_abi_version(void);
+/* Which sources this binary was compiled from: the first 16 hex digits of the SHA-256 over csrc/ + this header + the compiler flags,
+ * baked in at build time (lidar_object_detection_amd/_build.py: source_id).  The loader compares it with the sources beside it and
+ * rebuilds or refuses a stale library; bench.py prints it with every number.  "unknown" for a build made without the build script. */
+const char *lpf_build_id(void);
+/* Page-locked host memory (hipHostMalloc) for callers that are not torch programs: results copied into it are DMA transfers, and a
+ * frame loop that reuses it does not allocate per call.  NULL on failure (lpf_last_error(NULL)). */
+void *lpf_host_alloc(size_t bytes);
+void  lpf_host_free(void *p);
 int  lpf_create(lpf_ctx **out, int device_id);
 void lpf_destroy(lpf_ctx *ctx);
 const char *lpf_last_error(const lpf_ctx *ctx);      /* ctx may be NULL: error of the last failed lpf_create */

@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so
 travels to the GPU box with the repository snapshot.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -27,13 +28,41 @@ def hipcc():
     return exe
 
 
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "lpf.h")
+_MARKER = b"LPF_BUILD_ID="
+
+
+def source_id(lab=False):
+    """What a library built NOW would be built from: the first 16 hex digits of the SHA-256 over the sources of csrc/, include/lpf.h and
+    the compiler flags (-DLPF_LAB for the lab build).  It is compiled into the library (lpf_build_id()), so a binary can always be tied
+    to its sources: needs_build() and the loader compare the two, bench.py prints it with every number."""
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS + (["-DLPF_LAB"] if lab else [])).encode())
+    return h.hexdigest()[:16]
+
+
+def library_id(lib):
+    """The build id a library file carries (read from the file, nothing is loaded), or None: no file / a build without one."""
+    try:
+        with open(lib, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    i = data.find(_MARKER)
+    if i < 0:
+        return None
+    tail = data[i + len(_MARKER):i + len(_MARKER) + 16]
+    return tail.decode("ascii", "replace") if len(tail) == 16 and all(c in b"0123456789abcdef" for c in tail) else None
+
+
 def needs_build(lib=None):
+    """True unless `lib` was built from exactly the sources (and flags) that are here now.  Ids, not mtimes: a checkout, a copy to the
+    GPU box or a touched file changes the mtimes but not what the library is."""
     lib = lib or LIB
-    if not os.path.exists(lib):
-        return True
-    t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "lpf.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_id(lib) != source_id(lab=os.path.abspath(lib) == os.path.abspath(LAB_LIB))
 
 
 def torch_lib_dir():
@@ -64,7 +93,8 @@ def build(force=False, verbose=False, lab=False):
     os.makedirs(os.path.join(work, "stub"), exist_ok=True)
     obj = os.path.join(work, "lpf_api.o")
     compile_flags = [f for f in FLAGS if f not in ("-shared", "-pthread", "-ldl")]
-    cmds = [[hipcc()] + compile_flags + (["-DLPF_LAB"] if lab else []) + ["-c", os.path.join(CSRC, "lpf_api.hip"), "-o", obj]]
+    cmds = [[hipcc()] + compile_flags + (["-DLPF_LAB"] if lab else []) + ['-DLPF_BUILD_ID_STR="%s"' % source_id(lab),
+                                                                          "-c", os.path.join(CSRC, "lpf_api.hip"), "-o", obj]]
     if verbose:
         print(" ".join(cmds[0]))
     subprocess.check_call(cmds[0], cwd=CSRC)

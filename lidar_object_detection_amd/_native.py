@@ -51,27 +51,59 @@ _libs = {}
 
 
 def library_path():
-    """liblpf.so of this package; LPF_LIBRARY names another build of the same ABI (lab builds: tools/)."""
-    return os.environ.get("LPF_LIBRARY") or _build.LIB
+    """liblpf.so of this package.  LPF_LIBRARY names another build of the same ABI, and is honoured ONLY in lab runs (LPF_LAB=1 in the
+    environment, which `bench.py --lab ...` and the tools set): a stray variable must not silently swap the library a number or a
+    test is made with."""
+    env = os.environ.get("LPF_LIBRARY")
+    if env:
+        if os.environ.get("LPF_LAB") != "1":
+            raise LpfError(-3, "LPF_LIBRARY=%s is set but this is not a lab run (LPF_LAB=1; bench.py --lab ...): refusing to load another "
+                               "library in place of %s" % (env, _build.LIB))
+        return env
+    return _build.LIB
+
+
+def _own(path):
+    """lab flag if `path` is one of this package's two libraries (they are tied to the sources beside them), else None"""
+    for lib, lab in ((_build.LIB, False), (_build.LAB_LIB, True)):
+        if os.path.abspath(path) == os.path.abspath(lib):
+            return lab
+    return None
 
 
 def load(path=None):
-    """dlopen liblpf.so (or another build of the same ABI at ``path``); raises if it has not been built (never falls back)."""
+    """dlopen liblpf.so (or another build of the same ABI at ``path``).  The package's own libraries are tied to their sources: a
+    missing or STALE one (its compiled-in build id differs from _build.source_id()) is rebuilt with hipcc, and refused if that is
+    not possible -- never loaded as it is, and there is no CPU path to fall back to."""
     path = os.path.abspath(path or library_path())
     if path in _libs:
         return _libs[path]
-    # A process that also uses PyTorch must end up with ONE HIP runtime.  The torch wheel bundles its own libamdhip64.so;
-    # if liblpf.so pulls in the system copy first, torch's later initialisation fails ("No HIP GPUs are available").
-    # Importing torch first makes its copy the one both use (same SONAME).  LPF_NO_TORCH_PRELOAD=1 skips this.
-    if "torch" not in sys.modules and not os.environ.get("LPF_NO_TORCH_PRELOAD"):
+    lab = _own(path)
+    if lab is not None and _build.needs_build(path):
+        have = _build.library_id(path)
         try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+            _build.build(lab=lab)
+        except Exception as e:
+            raise LpfError(-2, "%s is %s and cannot be rebuilt here (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU path" % (
+                                   path, "missing" if not os.path.exists(path) else "stale (built from sources %s, these are %s)" % (have, _build.source_id(lab)), e))
     if not os.path.exists(path):
         raise LpfError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU path" % path)
     lib = ctypes.CDLL(path)
+    build_id = None
+    if hasattr(lib, "lpf_build_id"):
+        lib.lpf_build_id.restype = ctypes.c_char_p
+        build_id = (lib.lpf_build_id() or b"").decode()
+    if lab is not None and build_id != _build.source_id(lab):
+        raise LpfError(-2, "%s reports build id %s, the sources beside it are %s: refusing a library that is not built from them" % (
+            path, build_id, _build.source_id(lab)))
+    lib._lpf_info = {"path": path, "build_id": build_id}
+    if hasattr(lib, "lpf_host_alloc"):
+        lib.lpf_host_alloc.restype = _P
+        lib.lpf_host_alloc.argtypes = [ctypes.c_size_t]
+        lib.lpf_host_free.restype = None
+        lib.lpf_host_free.argtypes = [_P]
     lib.lpf_last_error.restype = ctypes.c_char_p
     lib.lpf_last_error.argtypes = [_P]
     lib.lpf_create.argtypes = [ctypes.POINTER(_P), ctypes.c_int]
@@ -121,7 +153,7 @@ def load(path=None):
     return lib
 
 
-EXPORTED = ("lpf_abi_version", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
+EXPORTED = ("lpf_abi_version", "lpf_build_id", "lpf_host_alloc", "lpf_host_free", "lpf_create", "lpf_destroy", "lpf_last_error", "lpf_set_stream", "lpf_use_own_stream", "lpf_wait_for_stream",
             "lpf_release_to_stream", "lpf_sync",
             "lpf_set_pipelined", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_mask_rects", "lpf_set_label_image",
@@ -234,6 +266,7 @@ class LpfContext:
 
     def __init__(self, device=0, library=None):
         self._lib = load(library)
+        self.library = dict(self._lib._lpf_info)            # {"path", "build_id"}: which binary, built from which sources
         h = _P()
         rc = self._lib.lpf_create(ctypes.byref(h), int(device))
         if rc != 0:
@@ -263,6 +296,9 @@ class LpfContext:
                 r.close()
             self._lib.lpf_destroy(self._h)
             self._h = None
+            for p, _, _ in self._pin.values():              # (views handed out earlier must not be used after close)
+                self._lib.lpf_host_free(p)
+            self._pin = {}
 
     def __del__(self):
         try:
@@ -408,7 +444,13 @@ class LpfContext:
             shape = tuple(masks.shape)
             out = torch.empty(shape[:-2] + (self.H, self.W), dtype=torch.uint8, device=masks.device)
             n = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+            # Ordering (include/lpf.h, "Ordering contract"): the masks -- and the cast above, and the memory torch's caching allocator
+            # just handed out for `out` -- belong to torch's current stream; the kernel runs on the context's.  An edge in, an edge
+            # out: the caller may use `out` on torch's stream at once (a no-op when the context shares that stream).
+            ts = torch.cuda.current_stream(masks.device).cuda_stream
+            self.wait_for_stream(ts)
             self._check(self._lib.lpf_resize_masks_u8(self._h, _dev_ptr(masks) if n else None, n, shape[-2], shape[-1], _dev_ptr(out) if n else None, 1))
+            self.release_to_stream(ts)
             return out
         a = np.asarray(masks)
         a = np.ascontiguousarray(a.astype(np.uint8))
@@ -626,14 +668,21 @@ class LpfContext:
         return self.run_batch([points], **kw)[0]
 
     def _pinned(self, name, shape, dtype):
-        """A persistent page-locked host array of the context (grow-only): copies from the GPU into it are DMA transfers the
-        call does not stage through pageable memory, and a frame loop does not allocate (and page in) megabytes per call."""
-        import torch
+        """A persistent page-locked host array of the context (grow-only; lpf_host_alloc = hipHostMalloc, no torch involved): copies
+        from the GPU into it are DMA transfers the call does not stage through pageable memory, and a frame loop does not allocate
+        (and page in) megabytes per call."""
         need = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        buf = self._pin.get(name)
-        if buf is None or buf.numel() < need:
-            buf = self._pin[name] = torch.empty(max(need + need // 4, 4096), dtype=torch.uint8).pin_memory()
-        return buf.numpy()[:need].view(dtype).reshape(shape)
+        ent = self._pin.get(name)
+        if ent is None or ent[1] < need:
+            if ent is not None:
+                self._lib.lpf_host_free(ent[0])
+                del self._pin[name]
+            cap = max(need + need // 4, 4096)
+            p = self._lib.lpf_host_alloc(cap)
+            if not p:
+                raise LpfError(-4, (self._lib.lpf_last_error(None) or b"lpf_host_alloc failed").decode())
+            ent = self._pin[name] = (p, cap, np.frombuffer((ctypes.c_uint8 * cap).from_address(p), dtype=np.uint8))
+        return ent[2][:need].view(dtype).reshape(shape)
 
     def run_batch(self, frames, want_uv=True, want_label=True, want_float=False, want_lists=True,
                   inst_cap=None, want_valid_uv=False, pinned=False):

@@ -29,6 +29,11 @@
 #define LPF_TAIL_SPREAD_20THS 13
 #endif
 
+// K1 tile of a large software-pipelined launch whose tiles read the masks inside their rectangles (LpfDirectRect): 1024 points.
+// (2048, what the packed form uses there, needs more registers than the step kernel has -- the exact test of a candidate row computes
+//  its pixel again -- and measured slower on real scans even in a form that fitted: 146 frames per step 170 vs 158 us.)
+#define LPF_RECT_FUSED_TILE 1024
+
 static_assert(sizeof(lpf_frame_summary) == LPF_SUMMARY_BYTES, "summary layout is shared with lpf_finalize_frame");
 
 namespace {
@@ -108,6 +113,8 @@ struct lpf_ctx {
         DevBuf label_a, label_b;      // label images [F][H][W] uint32 (b = erosion ping-pong)
         void *label_cur = nullptr;
         int label_bytes = 4;          // element size of the label image: 1 (M <= 8), 2 (M <= 16) or 4
+        DevBuf rgrid;                 // candidate grid of the masks' rectangles (LpfDirectRect tiles), [F][cells] uint32
+        DevBuf rects;                 // lpf_set_mask_rects from host memory: the copy this set's run reads (its tiles may run a launch later)
         DevBuf tab;                   // [frames | segs | blks]
         std::vector<LpfFrame> tab_frames;         // the frame table `tab` holds (empty: none)
         size_t o_segs = 0, o_blks = 0, o_cblks = 0;
@@ -125,7 +132,8 @@ struct lpf_ctx {
         int nk1 = 0, lb = 4;              // (pend_k1) K1 tiles, label element size
         bool small = false;
         bool direct = false;              // its tiles read the lent masks themselves (LpfDirect; small launches)
-        int dsel = 0;                     // ... under membership rule 0 (uint8) or 1..3 (float)
+        int dsel = 0;                     // ... under membership rule 0 (uint8) or 1..3 (float); 4 / 5: inside the masks' rectangles only
+                                          // (LpfDirectRect, launches of any size: uint8 rule 0 / float rule 1)
     } pend_k1, pend_tail, pend_fin;
     bool fused = false;               // pipelined: one launch per run (modes 2 / 4)
     // Mode 4: the mask pack rides as well -- the launch of run i carries the pack of run i's masks, the K1 tiles of run i-1
@@ -139,7 +147,7 @@ struct lpf_ctx {
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // lpf_set_mask_rects: rectangles for the NEXT lpf_set_masks_* (device pointer: the caller's, or rects_buf), consumed by it
     DevBuf resize_buf;                // lpf_resize_masks_u8: weight tables (+ staging for host callers)
-    DevBuf rects_buf; const int4 *rects_pending = nullptr; int rects_F = 0, rects_M = 0;
+    const int4 *rects_pending = nullptr; int rects_F = 0, rects_M = 0;
     DevBuf lab_clk;                   // LPF_LAB builds (lpf_lab_role_clock): 6 roles x 5 counters, or empty
     int geometry = 0;                 // LPF_LAB builds (lpf_set_geometry): 0 by launch size, 1 small, 2 large, 3 large + scan-kernel prefixes, 4 small + narrow tail
 
@@ -232,10 +240,18 @@ int launch_box_job(lpf_ctx *c, lpf_ctx::BoxSet &B)
 // in c->ride behind the tiles (label elements of pack_lb bytes; K's when K is there: the host keeps the two equal).  Any of
 // the roles may be absent.  `after` is recorded behind the launch.
 int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &Q, const lpf_ctx::Pending &R, bool ride, int pack_lb,
-                lpf_ctx::BoxSet *XB, hipEvent_t after)
+                lpf_ctx::BoxSet *XB, hipEvent_t after, const LpfRectJob *RG = nullptr)
 {
     static const LpfParams none = {};                      // unused roles get a well-formed struct
     static const LpfBoxJob nojob = {};
+    if (KK.valid && KK.direct && KK.dsel >= 4 && Q.valid && Q.pre) {
+        // tiles that read the masks inside their rectangles exist without the scan-kernel form of the riding tail (frames of more than
+        // 16.7 M points: rare): that tail and the summaries go in a launch of their own, ahead of the tiles
+        static const lpf_ctx::Pending nobody = lpf_ctx::Pending();
+        int rc_ = launch_step(c, nobody, Q, R, false, pack_lb, nullptr, nullptr);
+        if (rc_) return rc_;
+        return launch_step(c, KK, nobody, nobody, ride, pack_lb, XB, after, RG);
+    }
     const LpfParams &KP = KK.valid ? KK.P : none, &QP = Q.valid ? Q.P : none, &RP = R.valid ? R.P : none;
     const int k_lb = KK.valid ? KK.lb : pack_lb;
     LpfStepLayout Y;
@@ -252,6 +268,10 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     const LpfBoxJob &XJ = boxes ? XB->job : nojob;
     Y.nbox = boxes ? box_job_blocks(*XB) : 0;
     Y.nbox8 = (Y.nbox + 7) & ~7;
+    static const LpfRectJob norect = {};
+    const LpfRectJob &GJ = RG ? *RG : norect;
+    Y.nrg = RG ? RG->F * RG->bpf : 0;
+    Y.nrg8 = (Y.nrg + 7) & ~7;
     Y.ntail = Q.valid ? Q.ntail : 0;
     Y.nk1 = KK.valid ? KK.nk1 : 0;
     Y.npack = 0;
@@ -273,16 +293,22 @@ int launch_step(lpf_ctx *c, const lpf_ctx::Pending &KK, const lpf_ctx::Pending &
     }
     const long long rest = (long long)nk1_pad - (long long)Y.nper * Y.kper;
     Y.rest = (int)(rest > 0 ? rest : 0);
-    const long long grid = (long long)Y.nfin8 + Y.nbox8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
+    const long long grid = (long long)Y.nfin8 + Y.nbox8 + Y.nrg8 + (long long)Y.nper * (Y.kper + 8) + Y.rest + Y.npack;
     if (grid > 0) {
         const dim3 gs((unsigned)grid);
         ++c->stats[3];
         if (boxes) ++c->stats[5];
-#define LPF_STEP_LAUNCH(RW, LT, PR) do { if (boxes) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, true>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ); \
-                                         else hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, false>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ); } while (0)
+#define LPF_STEP_LAUNCH(RW, LT, PR) do { if (boxes) hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, true>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ, GJ); \
+                                         else hipLaunchKernelGGL((lpf_step_t<RW, LPF_K1_FLAGS, LT, PR, false>), gs, dim3(LPF_BLOCK), 0, c->stream, KP, QP, RP, Y, J, XJ, GJ); } while (0)
 #define LPF_STEP_LT(RW, PR) do { if (k_lb == 1) LPF_STEP_LAUNCH(RW, uint8_t, PR); else if (k_lb == 2) LPF_STEP_LAUNCH(RW, uint16_t, PR); else LPF_STEP_LAUNCH(RW, uint32_t, PR); } while (0)
         const bool qpre = Q.valid && Q.pre;
         const int rows = KP.tile_pts >> 8;
+        if (KK.valid && KK.direct && KK.dsel >= 4) {       // tiles of any size that read the masks inside their rectangles (no pack, no label image)
+            typedef LpfDirectRect<uint8_t, 0> R0; typedef LpfDirectRect<float, 1> R1;
+#define LPF_STEP_RECT(RW) do { if (KK.dsel == 4) LPF_STEP_LAUNCH(RW, R0, false); else LPF_STEP_LAUNCH(RW, R1, false); } while (0)
+            if (rows == 2) LPF_STEP_RECT(2); else LPF_STEP_RECT(4);
+#undef LPF_STEP_RECT
+        } else
         if (KK.valid && KK.direct) {                       // small launch whose tiles read the lent masks themselves (no pack role beside it)
             typedef LpfDirect<uint8_t, 0> D0; typedef LpfDirect<float, 1> D1; typedef LpfDirect<float, 2> D2; typedef LpfDirect<float, 3> D3;
 #define LPF_STEP_DIRECT(D) do { if (qpre) LPF_STEP_LAUNCH(2, D, true); else LPF_STEP_LAUNCH(2, D, false); } while (0)
@@ -384,15 +410,18 @@ int upload(lpf_ctx *c, void *dst, const void *src, size_t bytes)
         for (hipEvent_t &e : R.ev) LPF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const size_t q = R.cap / 4, need = (bytes + 255) & ~(size_t)255;
-    if (need > q) {
+    if (need >= q) {
         int rc_ = sync_all(c);
         if (rc_) return rc_;
         LPF_HIP(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
         ++c->stats[6];
         return LPF_OK;
     }
+    // Invariant: head < cap, and head never rests on a quarter's end -- a piece that would fill its quarter exactly starts the
+    // next one instead (">=": every `need` and q are multiples of 256, so exact fills are the common case, not the rare one; with
+    // ">" the head walked to `cap` after 32768 small uploads and the next copy went past the ring).
     size_t cur = R.head / q;
-    if (R.head - cur * q + need > q) {                      // leave this quarter: it is reusable once what was queued from it has run
+    if (R.head - cur * q + need >= q) {                     // leave this quarter: it is reusable once what was queued from it has run
         LPF_HIP(c, hipEventRecord(R.ev[cur], c->stream));
         R.rec[cur] = true;
         cur = (cur + 1) & 3;
@@ -584,10 +613,11 @@ int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks
             // streaming pack, 16 pixels per lane; erosion (if any) then runs on the packed image
             const long long total16 = (long long)F * (long long)(hw / 16);
             const unsigned nb = (unsigned)((total16 + LPF_BLOCK - 1) / LPF_BLOCK);
+            // (rectangles: only where set_masks_impl accepted them -- uint8 rule 0 / float rule 1, no erosion)
             if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (sizeof(T) == 1 && erode_iters == 0) ? rects : (const int4 *)nullptr, c->W);
+                hipLaunchKernelGGL((lpf_pack16<T, 0, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, rects, c->W);
             else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (const int4 *)nullptr, c->W);
+                hipLaunchKernelGGL((lpf_pack16<T, 1, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, rects, c->W);
             else if (mode == 2)
                 hipLaunchKernelGGL((lpf_pack16<T, 2, LT>), dim3(nb), dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, (long long)hw, total16, (const int4 *)nullptr, c->W);
             else
@@ -596,13 +626,13 @@ int pack_typed(lpf_ctx *c, lpf_ctx::Scratch &S, hipStream_t ms, const T *d_masks
             const int fuse = erode_iters > 0 ? 1 : 0;
             left -= fuse;
             if (mode == 0)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 0, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 0, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse, rects);
             else if (mode == 1)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 1, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 1, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse, rects);
             else if (mode == 2)
-                hipLaunchKernelGGL((lpf_pack_erode<T, 2, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 2, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse, (const int4 *)nullptr);
             else
-                hipLaunchKernelGGL((lpf_pack_erode<T, 3, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse);
+                hipLaunchKernelGGL((lpf_pack_erode<T, 3, LT>), grid, dim3(LPF_BLOCK), 0, ms, d_masks, cur, M, c->H, c->W, fuse, (const int4 *)nullptr);
         }
         LPF_HIP(c, hipGetLastError());
         if (left > 0) {
@@ -652,7 +682,8 @@ int set_masks_impl(lpf_ctx *c, const T *masks, int F, int M, int mode, int erode
     }
     const int lb = (M <= 8) ? 1 : (M <= 16) ? 2 : 4;
     // rectangles given for these masks (lpf_set_mask_rects): used where uint8 masks are packed as they are; consumed either way
-    const int4 *rects = (sizeof(T) == 1 && mode == 0 && erode_iters == 0 && c->rects_F == F && c->rects_M == M) ? c->rects_pending : nullptr;
+    const int4 *rects = (((sizeof(T) == 1 && mode == 0) || (sizeof(T) == 4 && mode == 1)) && erode_iters == 0 && c->rects_F == F && c->rects_M == M &&
+                         c->W >= 16) ? c->rects_pending : nullptr;         // (W >= 16: a group of 16 pixels of the pack spans at most two rows)
     c->rects_pending = nullptr;
     c->ride.valid = false;
     if (c->fused && per_set && M > 0 && erode_iters == 0 && on_device == 2) {
@@ -694,9 +725,9 @@ int pack_masks_now(lpf_ctx *c, lpf_ctx::Scratch &S, const void *masks, bool f32,
     int rc;
     if (f32) {
         const float *m = (const float *)masks;
-        if (lb == 1) rc = pack_typed<float, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
-        else if (lb == 2) rc = pack_typed<float, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
-        else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur);
+        if (lb == 1) rc = pack_typed<float, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
+        else if (lb == 2) rc = pack_typed<float, uint16_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
+        else rc = pack_typed<float, uint32_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
     } else {
         const uint8_t *m = (const uint8_t *)masks;
         if (lb == 1) rc = pack_typed<uint8_t, uint8_t>(c, S, c->stream, m, F, M, mode, 0, &cur, rects);
@@ -734,6 +765,24 @@ extern "C" {
 
 int lpf_abi_version(void) { return LPF_ABI_VERSION; }
 
+// The sources this binary was compiled from (see include/lpf.h).  The marker string is what _build.library_id() looks for in
+// the file, so a stale library is recognised without loading it.
+#ifndef LPF_BUILD_ID_STR
+#define LPF_BUILD_ID_STR "unknown"
+#endif
+static const char lpf_build_marker[] = "LPF_BUILD_ID=" LPF_BUILD_ID_STR;
+const char *lpf_build_id(void) { return lpf_build_marker + 13; }
+
+void *lpf_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(nullptr, LPF_ERR_NOMEM, "lpf_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+void lpf_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int lpf_create(lpf_ctx **out, int device_id)
 {
     if (!out) return fail(nullptr, LPF_ERR_ARG, "lpf_create: out is NULL");
@@ -762,14 +811,14 @@ void lpf_destroy(lpf_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &S : c->sc) {
-        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.label_a, &S.label_b, &S.tab};
+        DevBuf *sb[] = {&S.vbal, &S.mbal, &S.seg_tab, &S.grp_tab, &S.frm_tab, &S.seg_pre, &S.cnt, &S.mlist, &S.label_a, &S.label_b, &S.tab, &S.rects, &S.rgrid};
         for (DevBuf *b : sb) release(*b);
     }
     for (auto &B : c->bx) {
         DevBuf *bb[] = {&B.boxp, &B.boxq, &B.cand, &B.corners, &B.enabled, &B.aux, &B.bframes, &B.stage};
         for (DevBuf *b : bb) release(*b);
     }
-    DevBuf *all[] = {&c->resize_buf, &c->rects_buf, &c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
+    DevBuf *all[] = {&c->resize_buf, &c->lab_clk, &c->mask_stage, &c->pib_box, &c->pib_pts, &c->pib_out, &c->boxprep, &c->dimg, &c->coll, &c->st_uvv, &c->st_labv, &c->st_pts, &c->st_uv, &c->st_label,
                      &c->st_depth, &c->st_uf, &c->st_vf, &c->st_valid, &c->st_inst, &c->st_count, &c->st_summary};
     for (DevBuf *b : all) release(*b);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -896,10 +945,13 @@ int lpf_set_mask_rects(lpf_ctx *c, const int32_t *rects, int on_device, int F, i
         c->rects_pending = (const int4 *)rects;
     } else {
         if (c->capturing) return LPF_OK;                    // (a copy from host memory is not captured: the hint is dropped)
-        int rc = reserve(c, c->rects_buf, bytes);
+        // the copy lives in the scratch set of the run these masks are for: in the pipelined modes that run's tiles may read the
+        // rectangles a launch after the NEXT run's have been uploaded (into the next set); stream-ordered behind the set's last run
+        DevBuf &rb = c->sc[c->fused ? c->parity : 0].rects;
+        int rc = reserve(c, rb, bytes);
         if (rc) return rc;
-        if ((rc = upload(c, c->rects_buf.p, rects, bytes))) return rc;      // stream-ordered behind every launch that read the buffer
-        c->rects_pending = (const int4 *)c->rects_buf.p;
+        if ((rc = upload(c, rb.p, rects, bytes))) return rc;
+        c->rects_pending = (const int4 *)rb.p;
     }
     c->rects_F = F; c->rects_M = M;
     return LPF_OK;
@@ -1167,11 +1219,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     //  half its image has pixels: a real scan, 110 k points on 530 k pixels, 29.9 -> 24.9 us per 20-frame batch in a pipelined
     //  stream; a synthetic 2 M-point cloud is better off with the pack riding, 21.8 vs 24.2 us)
     const bool sparse_frames = Ntot * 2 <= (int64_t)F * c->W * c->H;
-    const bool direct_fused = c->ride.valid && fused && small && sparse_frames && M > 0;
+    // ... and with the masks' rectangles (lpf_set_mask_rects) a launch of ANY size reads the masks inside them: no pack, no label image
+    const bool direct_rect_fused = c->ride.valid && fused && M > 0 && c->ride.rects && ((!c->ride.f32 && c->ride.mode == 0) || (c->ride.f32 && c->ride.mode == 1));
+    const bool direct_fused = direct_rect_fused || (c->ride.valid && fused && small && sparse_frames && M > 0);
     const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
     if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
-    const bool direct = M > 0 && c->lazy.valid && small && sparse_frames && !fused;
+    const bool direct_rect = M > 0 && c->lazy.valid && !fused && c->lazy.rects && ((!c->lazy.f32 && c->lazy.mode == 0) || (c->lazy.f32 && c->lazy.mode == 1));
+    const bool direct = direct_rect || (M > 0 && c->lazy.valid && small && sparse_frames && !fused);
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
     // The label image lives in the scratch set that was current when the masks were set.  A pipelined run must find it in its
     // own set (the sets rotate: masks are set before every run); any other run has nothing owed and reads it where it is.
@@ -1179,6 +1234,20 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (M > 0 && fused && !direct && c->mask_set != c->parity)
         return fail(c, LPF_ERR_STATE, "the masks were set for another scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.label_img = (M > 0) ? (direct ? c->lazy.p : direct_fused ? c->ride.masks : SM.label_cur) : nullptr;
+    P.rects = direct_rect ? c->lazy.rects : direct_rect_fused ? c->ride.rects : nullptr;
+    // ... whose tiles look a point's candidates up in a coarse grid of the rectangles (a few KB per frame), built once per run: by
+    // blocks of this run's own launch where the tiles come a launch later (mode 4), else by a small kernel ahead of the tiles
+    LpfRectJob RG;
+    memset(&RG, 0, sizeof RG);
+    const bool rect_tiles = P.rects != nullptr;
+    if (rect_tiles) {
+        RG.rects = P.rects; RG.F = F; RG.M = M;
+        RG.cw = (c->W + LPF_RG_CELL - 1) / LPF_RG_CELL; RG.ch = (c->H + LPF_RG_CELL - 1) / LPF_RG_CELL;
+        RG.cells = RG.cw * RG.ch; RG.bpf = (RG.cells + LPF_BLOCK - 1) / LPF_BLOCK;
+        if ((rc = reserve(c, S.rgrid, (size_t)F * RG.cells * sizeof(uint32_t)))) return rc;
+        RG.grid = (uint32_t *)S.rgrid.p;
+        P.rect_grid = RG.grid; P.rg_cw = RG.cw; P.rg_cells = RG.cells;
+    }
     if (M > 0 && !P.label_img) return fail(c, LPF_ERR_STATE, "no masks for this run's scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.boxp = (const double *)BX.boxp.p; P.boxq = (const float *)BX.boxq.p;
     P.cand = (const unsigned long long *)BX.cand.p;
@@ -1187,6 +1256,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.seg_pre = pre_scan ? (uint4 *)S.seg_pre.p : nullptr;
     P.cnt = (unsigned *)S.cnt.p;
     P.nblk = nblk; P.ncblk = ncblk; P.csplit = csplit; P.lists_small = few ? 1 : 0; P.count_boxes = count_boxes ? 1 : 0;
+    P.count_lazy = small ? 0 : 1;
 
     // ---- buffers: caller's HBM pointers, or internal staging for host callers -----------
     const size_t n = (size_t)Ntot;
@@ -1242,7 +1312,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     P.tile_pts = small ? 512 : 1024;
     // the fused launch shares the chip with the previous run's tail blocks: 2048-point tiles keep twice the loads in flight
     // per wave, so the streaming work holds its bandwidth on fewer resident blocks (measured: 104.9 vs 108.8 us per step)
-    if (fused && !small) P.tile_pts = 2048;
+    if (fused && !small) P.tile_pts = direct_rect_fused ? LPF_RECT_FUSED_TILE : 2048;
     const int nk1 = nseg_total * (int)(seg_pts / P.tile_pts);
     const int lb = (M > 0) ? SM.label_bytes : 4;
     const bool want_lists = out->valid_idx || out->inst_idx;
@@ -1250,6 +1320,12 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // mode 4: the mask pack and the tiles of one launch share the label element type -- else the pipeline is drained first
     if (fused && c->defer && c->pend_k1.valid && ride_pack && (c->pend_k1.direct || c->pend_k1.lb != lb) && (rc = flush_pending(c))) return rc;
+    // the candidate grid of the masks' rectangles: where this run's tiles are in this run's own launch(es) -- in order, mode 2 -- a
+    // small kernel ahead of them; in mode 4 it rides in the launch below (the tiles come a launch later)
+    if (rect_tiles && nk1 > 0 && !(fused && c->defer)) {
+        hipLaunchKernelGGL(lpf_rect_grid_kernel, dim3((unsigned)(RG.F * RG.bpf)), dim3(LPF_BLOCK), 0, c->stream, RG);
+        LPF_HIP(c, hipGetLastError());
+    }
     // (profiling brackets the launches that carry streaming tiles: in mode 4 the first launch after a drain carries none)
     const bool carries_k1 = (fused && c->defer) ? (c->pend_k1.valid && c->pend_k1.nk1 > 0) : (nk1 > 0 || fused);
     if (carries_k1 && c->profiling && c->ev_used < (1u << 16)) {
@@ -1270,9 +1346,9 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         //      the previous run's -- everything one launch later, nothing left on the stream between two steps.
         lpf_ctx::Pending cur;
         cur.valid = true; cur.P = P; cur.pre = pre_scan; cur.ntail = ntail; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
-        cur.direct = direct_fused; cur.dsel = c->ride.f32 ? c->ride.mode : 0;
+        cur.direct = direct_fused; cur.dsel = direct_rect_fused ? (c->ride.f32 ? 5 : 4) : c->ride.f32 ? c->ride.mode : 0;
         const lpf_ctx::Pending KK = c->defer ? c->pend_k1 : cur, Q = c->pend_tail, R = c->pend_fin;
-        if ((rc = launch_step(c, KK, Q, R, ride_pack, lb, &BX, e1))) return rc;
+        if ((rc = launch_step(c, KK, Q, R, ride_pack, lb, &BX, e1, (rect_tiles && c->defer) ? &RG : nullptr))) return rc;
         c->pend_fin = Q;                                   // its tail has just been launched: summaries in a later launch
         c->pend_tail = KK;
         if (c->defer) c->pend_k1 = cur;
@@ -1285,14 +1361,18 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         // that reads the tables follows in the next -- the same number of launches as with boxes that never change
         lpf_ctx::Pending cur, none;
         cur.valid = true; cur.P = P; cur.pre = false; cur.ntail = 0; cur.nk1 = nk1; cur.lb = lb; cur.small = small;
-        cur.direct = direct; cur.dsel = c->lazy.f32 ? c->lazy.mode : 0;
+        cur.direct = direct; cur.dsel = direct_rect ? (c->lazy.f32 ? 5 : 4) : c->lazy.f32 ? c->lazy.mode : 0;
         if ((rc = launch_step(c, cur, none, none, false, lb, &BX, e1))) return rc;
     } else {
     if ((rc = launch_box_job(c, BX))) return rc;           // (no tiles to ride with)
     if (nk1 > 0) {
         const dim3 g1((unsigned)nk1);
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
-        if (direct) {
+        if (direct_rect) {
+            typedef LpfDirectRect<uint8_t, 0> R0; typedef LpfDirectRect<float, 1> R1;
+            if (small) { if (!c->lazy.f32) LPF_K1_LAUNCH(2, R0); else LPF_K1_LAUNCH(2, R1); }
+            else       { if (!c->lazy.f32) LPF_K1_LAUNCH(4, R0); else LPF_K1_LAUNCH(4, R1); }
+        } else if (direct) {
             typedef LpfDirect<uint8_t, 0> D0; typedef LpfDirect<float, 1> D1; typedef LpfDirect<float, 2> D2; typedef LpfDirect<float, 3> D3;
             if (!c->lazy.f32) LPF_K1_LAUNCH(2, D0);
             else if (c->lazy.mode == 1) LPF_K1_LAUNCH(2, D1);
@@ -1390,7 +1470,10 @@ int lpf_points_in_boxes(lpf_ctx *c, const float *pts, int64_t k, int stride, con
 
 // OpenCV's weight table of one axis (resize.cpp: the xofs / alpha loop of resizeGeneric_, 8-bit INTER_LINEAR): per destination index
 // {source index, second source index, w0, w1}.  Every step is a separate IEEE operation (volatile: no contraction, no excess precision).
-static void resize_table(int n_dst, int n_src, std::vector<int4> &tab)
+// `clamp`: the x axis -- resize() sets {index, fraction} to {0, 0} / {n_src - 1, 0} beyond the ends.  The y axis keeps the fraction
+// and only clips the two row indices (resizeGeneric_Invoker: clip(sy + k, 0, h)), so an edge row is blended with itself under both
+// weights, whose two truncating shifts are not those of a single weight of 2048.
+static void resize_table(int n_dst, int n_src, bool clamp, std::vector<int4> &tab)
 {
     tab.resize((size_t)n_dst);
     volatile double ratio = (double)n_dst / (double)n_src;
@@ -1401,14 +1484,15 @@ static void resize_table(int n_dst, int n_src, std::vector<int4> &tab)
         volatile float f = (float)b;
         int s = (int)floorf(f);
         volatile float fr = f - (float)s;
-        if (s < 0) { s = 0; fr = 0.f; }
-        if (s >= n_src - 1) { s = n_src - 1; fr = 0.f; }
+        if (clamp && s < 0) { s = 0; fr = 0.f; }
+        if (clamp && s >= n_src - 1) { s = n_src - 1; fr = 0.f; }
         volatile float one_minus = 1.0f - fr;
         volatile float p0 = one_minus * 2048.0f, p1 = fr * 2048.0f;
         long w0 = lrintf(p0), w1 = lrintf(p1);              // round half to even (the default rounding mode), as cvRound
         w0 = w0 < -32768 ? -32768 : w0 > 32767 ? 32767 : w0;
         w1 = w1 < -32768 ? -32768 : w1 > 32767 ? 32767 : w1;
-        tab[(size_t)d] = make_int4(s, s + 1 < n_src ? s + 1 : n_src - 1, (int)w0, (int)w1);
+        const int s0 = s < 0 ? 0 : s > n_src - 1 ? n_src - 1 : s, s1 = s + 1 < 0 ? 0 : s + 1 > n_src - 1 ? n_src - 1 : s + 1;
+        tab[(size_t)d] = make_int4(s0, s1, (int)w0, (int)w1);
     }
 }
 
@@ -1418,8 +1502,10 @@ int lpf_resize_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, uin
     if (!c) return LPF_ERR_ARG;
     if (use_device(c)) return LPF_ERR_HIP;
     if (!c->have_camera) return fail(c, LPF_ERR_STATE, "lpf_set_camera has not been called (the target size is the camera's)");
-    if (n < 0 || h <= 0 || w <= 0 || (n > 0 && (!src || !dst)) || (long long)n * h * w > (1ll << 40))
-        return fail(c, LPF_ERR_ARG, "resize_masks: n=%d h=%d w=%d src=%p dst=%p", n, h, w, (const void *)src, (void *)dst);
+    if (n < 0 || h <= 0 || w <= 0 || (n > 0 && (!src || !dst)) || (long long)h * w > 0x7fffffffll || (long long)n * h * w > (1ll << 36) ||
+        (long long)n * c->W * c->H > (1ll << 36))
+        return fail(c, LPF_ERR_ARG, "resize_masks: n=%d h=%d w=%d src=%p dst=%p (a plane of at most 2^31 - 1 pixels -- the kernel indexes it with "
+                                    "32-bit arithmetic -- and at most 2^36 pixels in all, in and out)", n, h, w, (const void *)src, (void *)dst);
     if (n == 0) return LPF_OK;
     const int W = c->W, H = c->H;
     if (w == 2 * W && h == 2 * H)
@@ -1431,18 +1517,19 @@ int lpf_resize_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, uin
     const uint8_t *dS = src;
     uint8_t *dD = dst;
     std::vector<int4> xt, yt;
-    resize_table(W, w, xt);
-    resize_table(H, h, yt);
+    resize_table(W, w, true, xt);
+    resize_table(H, h, false, yt);
     const size_t tab_bytes = ((size_t)W + (size_t)H) * sizeof(int4);
     if ((rc = reserve(c, c->resize_buf, tab_bytes + (on_device ? 0 : in_bytes + out_bytes)))) return rc;
-    LPF_HIP(c, hipMemcpyAsync(c->resize_buf.p, xt.data(), (size_t)W * sizeof(int4), hipMemcpyHostToDevice, c->stream));
-    LPF_HIP(c, hipMemcpyAsync((char *)c->resize_buf.p + (size_t)W * sizeof(int4), yt.data(), (size_t)H * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    // the tables are host vectors of this call: they travel through the pinned ring (copied now, queued in stream order), so a
+    // device-mode call returns without waiting for the GPU
+    if ((rc = upload(c, c->resize_buf.p, xt.data(), (size_t)W * sizeof(int4)))) return rc;
+    if ((rc = upload(c, (char *)c->resize_buf.p + (size_t)W * sizeof(int4), yt.data(), (size_t)H * sizeof(int4)))) return rc;
     if (!on_device) {
         dS = (const uint8_t *)c->resize_buf.p + tab_bytes;
         dD = (uint8_t *)c->resize_buf.p + tab_bytes + in_bytes;
         LPF_HIP(c, hipMemcpyAsync((void *)dS, src, in_bytes, hipMemcpyHostToDevice, c->stream));
     }
-    LPF_HIP(c, host_wait(c));                              // (the tables are host vectors of this call)
     if ((h == H && w == W)) {
         LPF_HIP(c, hipMemcpyAsync(dD, dS, out_bytes, hipMemcpyDeviceToDevice, c->stream));       // cv2.resize to the same size copies
     } else {

@@ -69,6 +69,9 @@ struct LpfParams {
                                  // software-pipelined launches, whose longest chain is a count block on a car)
     const float4 *pts;
     const void *label_img;       // [F][H][W] label image (uint8 / uint16 / uint32 elements, see LT) or null
+    const int4 *rects;           // [F][M] {x0, y0, x1, y1} (half open) of the masks (LpfDirectRect tiles only): a mask is read as zero outside
+    const uint32_t *rect_grid;   // [F][rg_cells] per cell of LPF_RG_CELL x LPF_RG_CELL pixels: the masks whose rectangle meets the cell (lpf_rect_grid_block)
+    int rg_cw, rg_cells;         // cells per row of the grid, cells per frame
     const double *boxp;          // [Btot][16] exact box parameters
     const float *boxq;           // [Btot][8]  conservative float AABB {lo xyz, hi xyz}
     const unsigned long long *cand;   // per (frame, 64-box word) a ground grid (LPF_GRID_WORDS words): see lpf_box_frame_block
@@ -93,6 +96,10 @@ struct LpfParams {
     float4 *mlist;               // [Ntot] per K1 wave (64*ROWS points), at the wave's first slot: {x, y, z, label
                                  // bits} of its masked points in point order (nothing gathers from the cloud later)
     int count_boxes;             // 1: the tail launch carries the box-count blocks
+    int count_lazy;              // 1: a count block first looks whether its segments hold a masked point at all and leaves if not -- before it
+                                 // stages its word's boxes (10 KB).  Large launches of real scans: most groups of segments hold none (the
+                                 // cars are a few per cent of a scan), and a frame with 300 boxes has five blocks per group.  Small
+                                 // launches keep both loads in one round trip: there the longest block is what counts.
     int tile_pts;                // points per K1 tile of this launch (4 waves)
 };
 
@@ -230,6 +237,16 @@ template <typename T, int MODE> struct LpfDirect { };        // tag: label bits 
 template <typename LT> struct LpfIsDirect { static constexpr bool value = false; };
 template <typename T, int MODE> struct LpfIsDirect<LpfDirect<T, MODE> > { static constexpr bool value = true; };
 
+// ... and with the masks' rectangles (lpf_set_mask_rects: a detector hands out every mask with its 2D box): a valid point is tested
+// against the frame's <= 32 rectangles (wave-uniform scalar loads) and reads mask m only inside rectangle m -- launches of ANY size then
+// run no pack and write no label image.  A real frame's five masks are 2.6 MB of which a few per cent lie inside the boxes, and a
+// fifth of its points are valid but only a few per cent of them fall into a rectangle: 146 real frames per step moved 743 MB per launch
+// (PMC) of which 88 were the pack's and ~40 the tiles' label look-ups, against 474 of strict point traffic.
+template <typename T, int MODE> struct LpfDirectRect { };
+template <typename LT> struct LpfIsDirectRect { static constexpr bool value = false; };
+template <typename T, int MODE> struct LpfIsDirectRect<LpfDirectRect<T, MODE> > { static constexpr bool value = true; };
+template <typename T, int MODE> struct LpfIsDirect<LpfDirectRect<T, MODE> > { static constexpr bool value = true; };     // (no pack beside such tiles)
+
 template <typename LT>
 struct LpfLabelSrc {                                         // packed label image [F][H][W] of LT
     typedef LT elem;
@@ -256,6 +273,14 @@ struct LpfLabelSrc<LpfDirect<T, MODE> > {                    // masks [F][M][H][
     static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.M * (size_t)P.W * (size_t)P.H; }
 };
 
+template <typename T, int MODE>
+struct LpfLabelSrc<LpfDirectRect<T, MODE> > {                // masks [F][M][H][W] of T, read inside their rectangles only (lpf_k1_tile)
+    typedef T elem;
+    static constexpr int mode = MODE;
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__, const LpfParams &, const int) { return 0u; }      // (not used)
+    static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.M * (size_t)P.W * (size_t)P.H; }
+};
+
 // ------------------------------------------------------------------------------------
 // K1: one block = one tile of 256*ROWS consecutive points of one frame (a segment of 4096 points is 4 or 8
 // tiles); a wave owns ROWS consecutive rows of 64 points.  All float4 loads of a lane are issued before the
@@ -273,6 +298,10 @@ struct LpfLabelSrc<LpfDirect<T, MODE> > {                    // masks [F][M][H][
 
 #define LPF_F_LAB_NOBAL 64u
 #define LPF_F_LAB_NOTAB 128u
+
+#define LPF_RG_SHIFT 4            // cells of the candidate grid of LpfDirectRect tiles: 16 x 16 pixels
+#define LPF_RG_CELL (1 << LPF_RG_SHIFT)
+__device__ __forceinline__ unsigned lpf_wave_or(unsigned x);
 
 template <int ROWS, unsigned FL, typename LT>
 __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, unsigned *s_cnt)
@@ -318,6 +347,36 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
         }
         uint32_t lab[ROWS];
         bool valid[ROWS];
+        constexpr bool RECT = LpfIsDirectRect<LT>::value;
+        const int4 *__restrict__ rc_f = RECT ? P.rects + (size_t)f * P.M : nullptr;
+        const uint32_t *__restrict__ rgrid = (RECT && limg && P.rect_grid) ? P.rect_grid + (size_t)f * P.rg_cells : nullptr;
+        const size_t mhw = (size_t)P.W * (size_t)P.H;
+        unsigned long long myv = 0, mym = 0;                // lane r keeps the ballots of row r
+        // what happens to a row once its label bits are known: label store, the two ballots, the hand-off entries of its masked
+        // points, the per-instance counts.  Tiles that gather from a label image do this in a second loop, after every row's gather
+        // has been issued; RECT tiles know a row's bits at once and keep nothing per row (no lab[] / valid[]: registers).
+        auto consume = [&](const int r, uint32_t l, const bool okr) {
+            const int idx = wbase + r * 64;
+            if (idx < seg_end && P.label_bits && !(FL & LPF_F_LAB_NOSTORE)) {
+                if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + fr.pt_off + idx);
+                else P.label_bits[fr.pt_off + idx] = l;
+            }
+            const unsigned long long vb = __ballot(okr);
+            const unsigned long long mb = __ballot(l != 0);
+            if (lane == r) { myv = vb; mym = mb; }
+            // the wave's masked points {x, y, z, label}, compacted in point order at the wave's own
+            // first slots: the tail reads them back in runs instead of gathering from the cloud
+            if (l && P.mlist && !(FL & LPF_F_LAB_NOSTORE))
+                P.mlist[fr.pt_off + (wbase - lane) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
+                    make_float4(p[r].x, p[r].y, p[r].z, __uint_as_float(l));
+            nvalid_w += __popcll(vb);
+            nmask_w += __popcll(mb);
+            while (l) {                                     // rare: per-instance counts
+                const int m = __ffs(l) - 1;
+                l &= l - 1;
+                atomicAdd(&s_cnt[2 + m], 1u);
+            }
+        };
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int idx = wbase + r * 64;
@@ -339,6 +398,11 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
             valid[r] = ok;
             // K4: label gather (2.1 MB image, L2 resident); consumed after the loop
             lab[r] = 0;
+            if constexpr (RECT) {
+                // candidates: the masks whose rectangle meets the point's cell of the frame's coarse grid -- one 4-byte gather from a
+                // table of a few KB (L1 / L2 resident), issued for every row before any is consumed, like the label-image gather
+                if (ok && rgrid) lab[r] = rgrid[(vi >> LPF_RG_SHIFT) * P.rg_cw + (ui >> LPF_RG_SHIFT)];
+            } else
             if (!(FL & LPF_F_LAB_NOGATHER)) {
                 if (ok && limg) lab[r] = Src::get(limg, P, vi * P.W + ui);
             }
@@ -358,30 +422,34 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
                 if (P.vf) P.vf[g] = vf;
             }
         }
-        unsigned long long myv = 0, mym = 0;                // lane r keeps the ballots of row r
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int idx = wbase + r * 64;
             uint32_t l = lab[r];
-            if (idx < seg_end && P.label_bits && !(FL & LPF_F_LAB_NOSTORE)) {
-                if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + fr.pt_off + idx);
-                else P.label_bits[fr.pt_off + idx] = l;
+            if constexpr (RECT) {
+                // Candidates -> label bits: only a row that has any (a few per cent of a real scan's rows: the cells around the cars)
+                // takes the exact test -- the pixel again (not kept per row: registers), rectangle m from a scalar load, and the
+                // bytes of mask m for the lanes inside it: a scalar base and a 32-bit offset per lane.  A mask counts inside its
+                // rectangle only, pixel for pixel.
+                if (__any(l != 0u)) {                        // (wave-uniform)
+                    double uf, vf, d;
+                    lpf_project_point(P, p[r].x, p[r].y, p[r].z, uf, vf, d);
+                    const int ui = lpf_sat_i32(rint(uf)), vi = lpf_sat_i32(rint(vf));
+                    const unsigned pix = (unsigned)(vi * P.W + ui);
+                    uint32_t any = lpf_wave_or(l), l2 = 0u;
+                    while (any) {                           // (wave-uniform: the masks that are a candidate of some lane)
+                        const int m = __ffs(any) - 1;
+                        any &= any - 1u;
+                        const int4 q = rc_f[m];             // scalar load
+                        const bool in = ((l >> m) & 1u) && ui >= q.x && ui < q.z && vi >= q.y && vi < q.w;
+                        if (__any(in)) {
+                            const typename Src::elem *__restrict__ mk = limg + (size_t)m * mhw;
+                            if (in && lpf_member<typename Src::elem, Src::mode>(mk[pix])) l2 |= 1u << m;
+                        }
+                    }
+                    l = l2;
+                }
             }
-            const unsigned long long vb = __ballot(valid[r]);
-            const unsigned long long mb = __ballot(l != 0);
-            if (lane == r) { myv = vb; mym = mb; }
-            // the wave's masked points {x, y, z, label}, compacted in point order at the wave's own
-            // first slots: the tail reads them back in runs instead of gathering from the cloud
-            if (l && P.mlist && !(FL & LPF_F_LAB_NOSTORE))
-                P.mlist[fr.pt_off + (wbase - lane) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
-                    make_float4(p[r].x, p[r].y, p[r].z, __uint_as_float(l));
-            nvalid_w += __popcll(vb);
-            nmask_w += __popcll(mb);
-            while (l) {                                     // rare: per-instance counts
-                const int m = __ffs(l) - 1;
-                l &= l - 1;
-                atomicAdd(&s_cnt[2 + m], 1u);
-            }
+            consume(r, l, valid[r]);
         }
         if (lane < ROWS && !(FL & LPF_F_LAB_NOBAL)) {       // one contiguous 8*ROWS-byte store per array
             const size_t row = (size_t)sid * rows_per_seg + ((c - seg_start) >> 6) + wave * ROWS + lane;
@@ -399,10 +467,14 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
             if (v) {
                 // three levels -- segment, group of 64 segments, frame (8 shards) -- so that a list wave finds its
                 // segment's place in the frame's lists with two wave sums instead of a scan over the frame
-                const int k = sid - fr.seg_off, g = tid >> 1, h = tid & 1;
+                // (the record's fields for this are read again here rather than kept in registers through the whole tile: the 8-row
+                //  tiles of the step kernel have none to spare)
+                int seg_off = P.frame0.seg_off, grp_off = P.frame0.grp_off, fid = P.frame0.pad;
+                if (P.F > 1) { const LpfFrame *e = P.segs + lpf_uni(sid); seg_off = e->seg_off; grp_off = e->grp_off; fid = e->pad; }
+                const int k = sid - seg_off, g = tid >> 1, h = tid & 1;
                 atomicAdd(reinterpret_cast<unsigned long long *>(P.seg_tab + (size_t)g * P.nseg_cap + sid) + h, v);
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.grp_tab + (size_t)g * P.ngrp_cap + fr.grp_off + (k >> 6)) + h, v);
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.frm_tab + ((size_t)f * LPF_FRM_SHARDS + (k & (LPF_FRM_SHARDS - 1))) * LPF_TAB_GROUPS + g) + h, v);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.grp_tab + (size_t)g * P.ngrp_cap + grp_off + (k >> 6)) + h, v);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.frm_tab + ((size_t)fid * LPF_FRM_SHARDS + (k & (LPF_FRM_SHARDS - 1))) * LPF_TAB_GROUPS + g) + h, v);
             }
         }
     }
@@ -1233,7 +1305,7 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
     lpf_count_entry(P, tb, first, f, nw, wd, part);
     const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
     if (wd * LPF_BC_WORD >= fr.B) return;                   // a frame without boxes in a batch that has some: no grid to look into (block-uniform)
-    lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.dom);
+    if (!P.count_lazy) lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.dom);
     {                                                       // the block's (up to) four segments: row prefixes -> LDS
         const int lane = lpf_lane();
         unsigned im = 0, mbase = 0, L = 0;
@@ -1242,6 +1314,11 @@ __device__ __forceinline__ void lpf_tail_block(const LpfParams &P, const int tb,
         if (lane == 0) LC.L[wave] = L;
     }
     __syncthreads();
+    if (P.count_lazy) {                                     // (block-uniform)
+        if ((LC.L[0] | LC.L[1] | LC.L[2] | LC.L[3]) == 0u) return;       // nothing to count: the boxes are never fetched
+        lpf_count_stage(P, fr, wd, tid, LPF_BLOCK, LC.cnt, LC.bq, LC.bp, LC.dom);
+        __syncthreads();
+    }
     // The chunks of 64 masked points of the four segments are shared: chunk c goes to wave (c mod 4 csplit) of the group's csplit
     // blocks.  Consecutive segments of a real scan lie on the same car -- all four heavy or all four empty -- so sharing within one
     // block gains nothing, sharing over four does (small pipelined launches: frame 100 in a stream 16 -> 12 us per frame).
@@ -1346,6 +1423,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_finalize(const LpfParams P)
 // they cost what they take):
 //     blocks [0, nfin8)                               summaries of run i-2 (nfin8 = frames, padded to a multiple of 8)
 //     then nbox8 box-job blocks                       (frames x 64-box words of the run being queued, padded)
+//     then nrg8 rectangle-grid blocks                 (mode 4, masks read inside their rectangles: the candidate grid of the run being queued)
 //     then nper periods of (kper K1 tiles, 8 tail blocks)
 //     then the remaining K1 tiles
 //     then the pack blocks
@@ -1359,6 +1437,7 @@ struct LpfStepLayout {
     int ntail;                   // tail blocks of run i-1
     int kper, nper;              // K1 tiles per period (multiple of 8), periods that carry tail blocks
     int nk1;                     // K1 tiles of run i
+    int nrg, nrg8;               // rectangle-grid blocks (mode 4, LpfDirectRect: of the run whose K1 tiles the NEXT launch carries), padded
     int npack;                   // mask-pack blocks (mode 4: of the run whose K1 tiles the NEXT launch carries), after all K1 tiles
     int rest;                    // K1 block slots after the periods
 #ifdef LPF_LAB
@@ -1421,9 +1500,34 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
                                                  const int M, const long long hw, const long long total16, const long long blk,
                                                  const int4 *__restrict__ rects, const int W);
 
+// Candidate grid of the masks' rectangles (LpfDirectRect tiles): cell (cy, cx) of frame f = the masks whose rectangle meets the
+// LPF_RG_CELL x LPF_RG_CELL pixels of the cell -- a superset of the masks a pixel of the cell can lie in.  A thread per cell, the
+// frame's rectangles from wave-uniform loads; a few KB per frame (1408 x 376: 2112 cells), built once per run: by blocks of the run's
+// own launch where its tiles come a launch later (lpf_set_pipelined 4), else by a small kernel ahead of them.
+struct LpfRectJob {
+    const int4 *rects;           // [F][M]
+    uint32_t *grid;              // [F][cells]
+    int F, M, cw, ch, cells, bpf;    // bpf: blocks per frame = ceil(cells / LPF_BLOCK)
+};
+__device__ __forceinline__ void lpf_rect_grid_block(const LpfRectJob &G, const int blk)
+{
+    const int f = blk / G.bpf, i = (blk - f * G.bpf) * LPF_BLOCK + (int)threadIdx.x;
+    if (f >= G.F || i >= G.cells) return;
+    const int cy = i / G.cw, cx = i - cy * G.cw;
+    const int x0 = cx << LPF_RG_SHIFT, y0 = cy << LPF_RG_SHIFT;
+    const int4 *__restrict__ rc = G.rects + (size_t)lpf_uni(f) * G.M;
+    uint32_t bits = 0u;
+    for (int m = 0; m < G.M; ++m) {
+        const int4 q = rc[m];
+        if (q.x < x0 + LPF_RG_CELL && q.z > x0 && q.y < y0 + LPF_RG_CELL && q.w > y0 && q.z > q.x && q.w > q.y) bits |= 1u << m;
+    }
+    G.grid[(size_t)f * G.cells + i] = bits;
+}
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_rect_grid_kernel(const LpfRectJob G) { lpf_rect_grid_block(G, (int)blockIdx.x); }
+
 template <int ROWS, unsigned FL, typename LT, bool PRE, bool BOXES>
 __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, const LpfParams Q, const LpfParams R, const LpfStepLayout Y,
-                                                           const LpfPackJob J, const LpfBoxJob X)
+                                                           const LpfPackJob J, const LpfBoxJob X, const LpfRectJob G)
 {
     __shared__ __attribute__((aligned(16))) char s_raw[LPF_STEP_LDS];
     __shared__ unsigned s_cnt[LPF_TAB_ROWS];
@@ -1445,6 +1549,11 @@ __global__ __launch_bounds__(LPF_BLOCK, 7) void lpf_step_t(const LpfParams P, co
         return;
     }
     b -= Y.nbox8;
+    if (b < Y.nrg8) {                                       // ---- candidate grid of the masks' rectangles of the run whose tiles come next launch
+        if (b < Y.nrg) lpf_rect_grid_block(G, b);
+        return;
+    }
+    b -= Y.nrg8;
     const int plen = Y.kper + 8, periodic = Y.nper * plen;
     int vblk;                                               // K1: virtual block index, (rank on the XCD) << 3 | XCD
     if (b < periodic) {
@@ -1868,8 +1977,26 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_job_kernel(const LpfBoxJob 
 // Requires hw % 16 == 0 and 16-byte aligned mask planes (checked on the host).
 // Mask rectangles (lpf_set_mask_rects): a detector hands out every mask with its 2D box and the mask is zero outside it
 // (ultralytics crops the masks to their boxes) -- a real frame's five masks are 2.6 MB of which a few per cent lie inside the boxes.
-// With the rectangles the pack reads a group of 16 pixels of mask m only where it meets m's rectangle; the label image is written
-// in full either way.  uint8 masks under rule 0 only (the other forms ignore the hint).
+// With the rectangles a mask is READ AS ZERO outside its rectangle, pixel for pixel: the pack reads a group of 16 pixels of mask m only
+// where it meets m's rectangle and keeps the pixels inside; the label image is written in full either way.  uint8 masks under rule 0
+// and float masks under rule 1, without erosion (the host passes no rectangles otherwise); tiles that read the masks themselves
+// honour the hint the same way (LpfDirectRect), so a result never depends on which of the two forms a launch takes.
+// which of the 16 pixels that start at (y, x) -- and run on into row y + 1 when the row ends first (W >= 16) -- lie inside rectangle r
+__device__ __forceinline__ unsigned lpf_rect_keep16(const int4 r, const int y, const int x, const int W)
+{
+    const int n0 = min(16, W - x);                          // pixels of the group on row y
+    unsigned k = 0u;
+    if (y >= r.y && y < r.w) {
+        const int lo = max(r.x - x, 0), hi = min(r.z - x, n0);
+        if (hi > lo) k = (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
+    }
+    if (n0 < 16 && y + 1 >= r.y && y + 1 < r.w) {           // (W not a multiple of 16: pixel i >= n0 is column i - n0 of the next row)
+        const int lo = max(r.x + n0, n0), hi = min(r.z + n0, 16);
+        if (hi > lo) k |= (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
+    }
+    return k & 0xFFFFu;
+}
+
 template <typename T, int MODE, typename LT>
 __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT *__restrict__ label,
                                                  const int M, const long long hw, const long long total16, const long long blk,
@@ -1885,26 +2012,32 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
     for (int i = 0; i < 16; ++i) bits[i] = 0;
     if (sizeof(T) == 1) {
         const int y = rects ? (int)(o / W) : 0, x = rects ? (int)(o - (long long)y * W) : 0;       // the group's first pixel
-        const bool whole = !rects || x + 16 > W;            // (a group that runs over the end of a row is read whatever the rectangles say)
         for (int m0 = 0; m0 < M; m0 += 8) {                 // eight independent 16-byte loads in flight
             uint4 q[8];
-            unsigned hm = 0xFFu;                            // masks of this round whose rectangle the group meets
-            if (!whole) {
-                hm = 0u;
+            // which of the group's 16 pixels lie inside mask j's rectangle, 16 bits per mask, two masks per register (the step kernel,
+            // of which this is a role, has no registers to spare): a mask is read as zero outside its rectangle, pixel for pixel -- as
+            // the tiles that read the masks themselves do (LpfDirectRect) -- and not read at all where the group misses the rectangle
+            unsigned kp[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (rects) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int4 r = rects[(size_t)f * M + min(m0 + j, M - 1)];
-                    if (y >= r.y && y < r.w && x + 16 > r.x && x < r.z) hm |= 1u << j;
+                    const unsigned k = lpf_rect_keep16(rects[(size_t)f * M + min(m0 + j, M - 1)], y, x, W);
+                    if (j & 1) kp[j >> 1] = (kp[j >> 1] & 0xFFFFu) | (k << 16); else kp[j >> 1] = (kp[j >> 1] & 0xFFFF0000u) | (k & 0xFFFFu);
                 }
-                if (hm == 0u) continue;                     // (most groups of a real frame: nothing to read, nothing to extract)
+                if ((kp[0] | kp[1] | kp[2] | kp[3]) == 0u) continue;          // (most groups of a real frame: nothing to read, nothing to extract)
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                q[j] = ((hm >> j) & 1u) ? *reinterpret_cast<const uint4 *>(mf + (size_t)min(m0 + j, M - 1) * hw) : make_uint4(0u, 0u, 0u, 0u);
+                q[j] = ((kp[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) ? *reinterpret_cast<const uint4 *>(mf + (size_t)min(m0 + j, M - 1) * hw) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (m0 + j < M && ((hm >> j) & 1u)) {
-                    const unsigned wv[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                const unsigned kj = (kp[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                if (m0 + j < M && kj) {
+                    unsigned wv[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                    if (rects && kj != 0xFFFFu) {           // the bytes outside the rectangle read as zero: 4 bits -> 4 byte masks per word
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) wv[w] &= ((((kj >> (4 * w)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         bits[i] |= (((wv[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 0u ? 1u : 0u) << (m0 + j);
@@ -1912,22 +2045,29 @@ __device__ __forceinline__ void lpf_pack16_block(const T *__restrict__ masks, LT
             }
         }
     } else {
+        const int y = rects ? (int)(o / W) : 0, x = rects ? (int)(o - (long long)y * W) : 0;
         for (int m0 = 0; m0 < M; m0 += 2) {
             float4 q[2][4];
+            unsigned kk[2] = {0xFFFFu, 0xFFFFu};            // pixels of the group inside the mask's rectangle (as above)
+            if (rects) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) kk[j] = lpf_rect_keep16(rects[(size_t)f * M + min(m0 + j, M - 1)], y, x, W);
+                if ((kk[0] | kk[1]) == 0u) continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    q[j][k] = *reinterpret_cast<const float4 *>(mf + (size_t)min(m0 + j, M - 1) * hw + 4 * k);
+                    q[j][k] = kk[j] ? *reinterpret_cast<const float4 *>(mf + (size_t)min(m0 + j, M - 1) * hw + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (m0 + j < M) {
+                if (m0 + j < M && kk[j]) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        bits[4 * k + 0] |= (lpf_member<float, MODE>(q[j][k].x) ? 1u : 0u) << (m0 + j);
-                        bits[4 * k + 1] |= (lpf_member<float, MODE>(q[j][k].y) ? 1u : 0u) << (m0 + j);
-                        bits[4 * k + 2] |= (lpf_member<float, MODE>(q[j][k].z) ? 1u : 0u) << (m0 + j);
-                        bits[4 * k + 3] |= (lpf_member<float, MODE>(q[j][k].w) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 0] |= ((lpf_member<float, MODE>(q[j][k].x) && ((kk[j] >> (4 * k + 0)) & 1u)) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 1] |= ((lpf_member<float, MODE>(q[j][k].y) && ((kk[j] >> (4 * k + 1)) & 1u)) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 2] |= ((lpf_member<float, MODE>(q[j][k].z) && ((kk[j] >> (4 * k + 2)) & 1u)) ? 1u : 0u) << (m0 + j);
+                        bits[4 * k + 3] |= ((lpf_member<float, MODE>(q[j][k].w) && ((kk[j] >> (4 * k + 3)) & 1u)) ? 1u : 0u) << (m0 + j);
                     }
                 }
             }
@@ -1968,7 +2108,7 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack16(const T *__restrict__ ma
 
 template <typename T, int MODE, typename LT>
 __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict__ masks, LT *__restrict__ label,
-                                                            int M, int H, int W, int erode)
+                                                            int M, int H, int W, int erode, const int4 *__restrict__ rects)
 {
     __shared__ uint32_t s_tile[LPF_TH + 2][LPF_TW + 2 + 1];
     const int f = blockIdx.z;
@@ -1982,8 +2122,13 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_pack_erode(const T *__restrict_
         if (y >= 0 && y < H && x >= 0 && x < W) {
             bits = 0;
             const size_t o = (size_t)y * W + x;
-            for (int m = 0; m < M; ++m)
+            for (int m = 0; m < M; ++m) {
+                if (rects) {                                // (lpf_set_mask_rects: a mask is read as zero outside its rectangle)
+                    const int4 r = rects[(size_t)f * M + m];
+                    if (!(x >= r.x && x < r.z && y >= r.y && y < r.w)) continue;
+                }
                 if (lpf_member<T, MODE>(mf[m * hw + o])) bits |= 1u << m;
+            }
         }
         s_tile[ty][tx] = bits;
     }

@@ -95,7 +95,10 @@ def cv2_resize_linear_u8(src, W, H):
       * per destination column dx: ``fx = float((dx + 0.5) * scale_x - 0.5)`` with ``scale_x = 1 / (double(W) / w)``;
         ``sx = floor(fx)``, ``fx -= sx``; ``sx < 0 -> sx = 0, fx = 0``; ``sx >= w - 1 -> sx = w - 1, fx = 0``;
         weights ``a0 = saturate_short(round_half_even((1 - fx) * 2048))``, ``a1 = saturate_short(round_half_even(fx * 2048))``;
-        the same per row with fy, b0, b1;
+      * per destination row dy: fy, sy, b0, b1 in the same way BUT WITHOUT the two clamps -- ``resize()`` only clamps in its x loop;
+        the row loop of ``resizeGeneric_Invoker`` keeps the fraction and clips the two ROW INDICES instead
+        (``clip(sy + k, 0, h)``), so a destination row above the first / below the last source row blends that row with itself
+        under both weights: ``((b0 * t) >> 16) + ((b1 * t) >> 16)``, whose two truncations are not those of ``(2048 * t) >> 16``;
       * horizontal pass, 32-bit: ``S = src[sx] * a0 + src[min(sx + 1, w - 1)] * a1`` (beyond the last source column: src[sx] * 2048);
       * vertical pass: ``dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2``.
     Not restated: the exact 2 x 2 decimation case, which OpenCV hands to INTER_AREA (raises NotImplementedError), and whatever a
@@ -107,22 +110,24 @@ def cv2_resize_linear_u8(src, W, H):
     if w == 2 * W and h == 2 * H:
         raise NotImplementedError("cv2.resize hands an exact 2 x 2 decimation to INTER_AREA")
 
-    def coeffs(n_dst, n_src):
+    def coeffs(n_dst, n_src, clamp):
         scale = 1.0 / (float(n_dst) / float(n_src))                       # double, as resize() computes it
         d = np.arange(n_dst, dtype=np.float64)
         f = ((d + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
-        lo = s < 0
-        s[lo] = 0; f[lo] = 0.0
-        hi = s >= n_src - 1
-        s[hi] = n_src - 1; f[hi] = 0.0
+        if clamp:                                                         # the x loop of resize(): index AND fraction
+            lo = s < 0
+            s[lo] = 0; f[lo] = 0.0
+            hi = s >= n_src - 1
+            s[hi] = n_src - 1; f[hi] = 0.0
         c0 = np.clip(np.rint((np.float32(1.0) - f) * np.float32(2048.0)), -32768, 32767).astype(np.int64)
         c1 = np.clip(np.rint(f * np.float32(2048.0)), -32768, 32767).astype(np.int64)
-        return s, np.minimum(s + 1, n_src - 1), c0, c1
+        # (rows: resizeGeneric_Invoker clips the indices only -- clip(sy + k, 0, h))
+        return np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1), c0, c1
 
-    sx, sx1, a0, a1 = coeffs(W, w)
-    sy, sy1, b0, b1 = coeffs(H, h)
+    sx, sx1, a0, a1 = coeffs(W, w, True)
+    sy, sy1, b0, b1 = coeffs(H, h, False)
     s = src.astype(np.int64)
     rows = s[:, sx] * a0[None, :] + s[:, sx1] * a1[None, :]                  # [h, W] 32-bit sums (<= 255 * 2048)
     S0, S1 = rows[sy], rows[sy1]                                             # [H, W]

@@ -1,7 +1,8 @@
-"""lpf_set_mask_rects: a hint -- "mask m of frame f is zero outside this rectangle" -- under which the pack of uint8 masks skips the
-16-pixel groups outside the rectangles.  With rectangles that hold, every output equals the run without them (and the CPU oracle);
-with rectangles that do NOT hold, the result is exactly that of masks zeroed in the groups the pack may skip -- which proves the
-skipping is really done, group by group, with the right edges."""
+"""lpf_set_mask_rects: a hint -- "mask m of frame f is zero outside this rectangle" -- under which a mask is READ AS ZERO outside its
+rectangle, pixel for pixel, by whichever form a launch takes: tiles that read the masks themselves inside the rectangles (launches of
+any size: no pack, no label image) or a pack that skips what lies outside.  With rectangles that hold, every output equals the run
+without them (and the CPU oracle); with rectangles that do NOT hold, the result is exactly that of masks zeroed outside their
+rectangles -- which proves the gating is really done, with the right edges, and that the forms agree."""
 import numpy as np
 import pytest
 
@@ -10,20 +11,15 @@ from oracle import cpu_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _skippable_zeroed(masks, rects, W):
-    """masks [F,M,H,W] with every 16-pixel group (linear over the image) that lies outside its mask's rectangle set to zero"""
-    out = masks.copy()
-    F, M, H, _ = masks.shape
-    flat = out.reshape(F, M, H * W)
-    for o in range(0, H * W, 16):
-        y, x = divmod(o, W)
-        if x + 16 > W:
-            continue                                        # a group over the end of a row is always read
-        for f in range(F):
-            for m in range(M):
-                x0, y0, x1, y1 = rects[f, m]
-                if not (y0 <= y < y1 and x + 16 > x0 and x < x1):
-                    flat[f, m, o:o + 16] = 0
+def _outside_zeroed(masks, rects):
+    """masks [F,M,H,W] with every pixel outside its mask's rectangle (x0, y0, x1, y1; half open) set to zero"""
+    out = np.zeros_like(masks)
+    F, M = masks.shape[:2]
+    for f in range(F):
+        for m in range(M):
+            x0, y0, x1, y1 = (int(v) for v in rects[f, m])
+            if x1 > x0 and y1 > y0:
+                out[f, m, max(y0, 0):y1, max(x0, 0):x1] = masks[f, m, max(y0, 0):y1, max(x0, 0):x1]
     return out
 
 
@@ -68,8 +64,10 @@ def test_rectangles_that_hold_change_nothing(calib, mode, rects_on_device):
 
 
 @pytest.mark.parametrize("mode", [False, "fused-pack"])
-@pytest.mark.parametrize("W,H", [(64, 24), (72, 32)])      # 72: groups of 16 pixels run over the ends of the rows
+@pytest.mark.parametrize("W,H", [(64, 24), (72, 32)])      # 72: the pack's groups of 16 pixels run over the ends of the rows
 def test_rectangles_that_do_not_hold_show_what_is_skipped(mode, W, H):
+    """host-memory runs: in order the tiles read the lent masks inside the rectangles; a pipelined context packs them (with the
+    rectangles) before a host-memory run -- the same result either way"""
     import torch
     from lidar_object_detection_amd._native import LpfContext
     rng = np.random.default_rng(5 + W)
@@ -88,7 +86,7 @@ def test_rectangles_that_do_not_hold_show_what_is_skipped(mode, W, H):
             x0, y0 = rng.integers(0, W - 4), rng.integers(0, H - 2)
             rects[f, m] = (x0, y0, rng.integers(x0 + 1, W + 1), rng.integers(y0 + 1, H + 1))
     rects[0, 0] = (0, 0, W, H); rects[0, 1] = (0, 0, 0, 0); rects[0, 2] = (15, 3, 16, 4); rects[0, 3] = (16, 0, 17, H)
-    expect = _skippable_zeroed(masks, rects, W)
+    expect = _outside_zeroed(masks, rects)
     assert (expect != masks).any()
     with LpfContext(0) as ctx:
         ctx.set_pipelined(mode)
@@ -105,8 +103,76 @@ def test_rectangles_that_do_not_hold_show_what_is_skipped(mode, W, H):
         assert np.array_equal(res[0]["label_bits"], o["label_bits"])
 
 
+@pytest.mark.parametrize("mode", [False, "fused", "fused-pack"])
+@pytest.mark.parametrize("kind", ["u8", "f32"])
+@pytest.mark.parametrize("size", ["large", "small"])
+def test_rectangles_that_do_not_hold_in_device_mode_launches_of_any_size(calib, mode, kind, size):
+    """Device-mode steps (the software-pipelined launches included): with the hint, tiles of ANY launch size read the lent masks inside
+    the rectangles only -- no pack rides, no label image is written.  Noise masks and rectangles that do not hold: every frame's
+    labels, lists and counts are those of the masks zeroed outside their rectangles.  uint8 masks and float masks (rule astype)."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    F, M = (5, 7) if size == "large" else (2, 7)
+    n = 900_000 if size == "large" else 60_000              # 4.5 M points: the large geometry (2048- / 1024-point tiles)
+    rng = np.random.default_rng(91 + F)
+    scs = [S.scene(n + 977 * f, n_masks=M, n_boxes=6, seed=8400 + f, calib=calib) for f in range(F)]     # (frames that do not start on a multiple of 64)
+    masks = (rng.random((F, M, H, W)) < 0.35).astype(np.uint8)
+    rects = np.zeros((F, M, 4), np.int32)
+    for f in range(F):
+        for m in range(M):
+            x0, y0 = rng.integers(0, W - 40), rng.integers(0, H - 20)
+            rects[f, m] = (x0, y0, rng.integers(x0 + 1, W + 1), rng.integers(y0 + 1, H + 1))
+    rects[0, 0] = (0, 0, W, H); rects[0, 1] = (0, 0, 0, 0); rects[0, 2] = (15, 3, 16, 4); rects[1, 0] = (5, 5, 4, 9)      # whole image, empty, one pixel, inverted
+    rects[1, 1] = rects[1, 2] = rects[1, 3] = (300, 50, 900, 300)                                                         # three rectangles on the same pixels
+    expect = _outside_zeroed(masks, rects)
+    sizes = [len(sc["points"]) for sc in scs]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ntot, cap = int(off[-1]), max(sizes)
+    boff = np.arange(F + 1, dtype=np.int32) * 6
+    d_pts = torch.from_numpy(np.concatenate([sc["points"] for sc in scs])).to(dev)
+    d_masks = torch.from_numpy(masks if kind == "u8" else masks.astype(np.float32)).to(dev)
+    d_rects = torch.from_numpy(rects).to(dev)
+    o = dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(ntot, dtype=torch.int32, device=dev),
+             valid_idx=torch.empty(ntot, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, cap), dtype=torch.int64, device=dev),
+             count_mb=torch.zeros(M * F * 6, dtype=torch.int32, device=dev), summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize(dev)
+    with LpfContext(0) as ctx:
+        ctx.set_pipelined(mode)
+        ctx.set_camera(T, K, W, H, 0.0, 40.0)
+        ctx.set_boxes([sc["corners_velo"] for sc in scs])
+        for k in range(3):                                  # (three runs: the pipelined modes' launches carry the roles of different runs)
+            if k == 1:
+                ctx.set_mask_rects(rects)                   # host memory: copied into the run's scratch set
+            else:
+                ctx.set_mask_rects(d_rects)
+            ctx.set_masks(d_masks, lend=True)
+            ctx.run_device(d_pts, off, inst_cap=cap, **o)
+            if k == 0:
+                ctx.stats(reset=True)                       # (the first run allocates)
+        st = ctx.stats()
+        ctx.sync()
+    sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+    lab, vidx, inst, cmb = o["label_bits"].cpu().numpy().view(np.uint32), o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy(), o["count_mb"].cpu().numpy()
+    for f, sc in enumerate(scs):
+        ref = orc.run(sc["points"], T, K, W, H, 0.0, 40.0, label_img=orc.pack_masks(expect[f], 0, H, W), M=M, corners=sc["corners_velo"], want_float=False)
+        a = int(off[f])
+        assert ref["inst_count"].sum() > 500 or f == 1
+        assert np.array_equal(lab[a:a + sizes[f]], ref["label_bits"]), (mode, kind, f)
+        assert np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"]), (mode, kind, f)
+        assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"]), (mode, kind, f)
+        for m in range(M):
+            lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+            assert np.array_equal(inst[f, lo:hi], ref["inst_lists"][m]), (mode, kind, f, m)
+        assert np.array_equal(cmb[M * 6 * f:M * 6 * (f + 1)].reshape(M, 6), ref["count_mb"]), (mode, kind, f)
+    if mode:
+        assert st["host_waits"] == 0, st
+
+
 def test_hint_is_ignored_where_masks_are_not_packed_as_they_are(calib):
-    """erosion, float masks, another shape: the rectangles (which do not hold here) change nothing"""
+    """erosion, float masks under the 0.5 rule, another shape: the rectangles (which do not hold here) change nothing"""
     import torch
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext

@@ -25,6 +25,15 @@ def test_restatement_on_hand_derived_values():
     S0 = 20 * 1024 + 40 * 1024; S1 = 100 * 1024 + 120 * 1024
     px = (((1536 * (S0 >> 4)) >> 16) + ((512 * (S1 >> 4)) >> 16) + 2) >> 2
     assert npp.cv2_resize_linear_u8(src, 3, 2)[0, 1] == px == 50
+    # a TOP-ROW edge pixel, by hand (the row loop of resizeGeneric_Invoker keeps the fraction and clips the row INDICES: dy = 0 of a
+    # doubling has fy = -0.25 -> sy = -1, fy = 0.75, rows clip(-1) = clip(0) = 0 under BOTH weights 512 and 1536).  x tripled: dx = 3 has
+    # fx = 3.5 / 3 - 0.5 = 0.667 -> a1 = round(0.667 * 2048) = 1365, so S = 1 * 1365, S >> 4 = 85:
+    # ((512 * 85) >> 16) + ((1536 * 85) >> 16) + 2 = 0 + 1 + 2 -> >> 2 = 0, where one weight of 2048 would give (2 + 2) >> 2 = 1
+    edge = np.array([[0, 1], [0, 1]], np.uint8)
+    assert ((((512 * (1365 >> 4)) >> 16) + ((1536 * (1365 >> 4)) >> 16) + 2) >> 2) == 0 and ((((2048 * (1365 >> 4)) >> 16) + 2) >> 2) == 1
+    got = npp.cv2_resize_linear_u8(edge, 6, 4)
+    assert got[:, 3].tolist() == [0, 0, 0, 0]           # (rows 1, 2 blend the two equal source rows under 1536 / 512: the same sum; a fraction
+                                                        #  clamped to 0 in rows 0 and 3 -- the x loop's rule -- would give [1, 0, 0, 1])
     # equal sizes: a copy; an exact 2 x 2 decimation is OpenCV's INTER_AREA case: refused
     assert np.array_equal(npp.cv2_resize_linear_u8(src, 4, 3), src)
     with pytest.raises(NotImplementedError):

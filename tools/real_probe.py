@@ -29,6 +29,11 @@ for name in ("frame_0000000100.npz", "frame_0000001461_full.npz", "frame_0000002
     frames.append(dict(points=np.ascontiguousarray(g["points"], dtype=np.float32),
                        masks=np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :W].astype(np.uint8),
                        cam0=np.ascontiguousarray(g["corners_cam0_raw"], dtype=np.float64)))
+if os.environ.get("PROBE_ALIGN"):                         # experiment: every frame padded to a multiple of PROBE_ALIGN points (a far point behind the camera)
+    q = int(os.environ["PROBE_ALIGN"])
+    for f in frames:
+        pad = (-len(f["points"])) % q
+        f["points"] = np.concatenate([f["points"], np.tile(np.array([[-500.0, 0.0, 0.0, 0.0]], np.float32), (pad, 1))])
 batch = [frames[i % 4] for i in range(nfr)]
 sizes = [len(f["points"]) for f in batch]
 off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -43,12 +48,15 @@ o = dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev), label_bits=to
          count_mb=torch.zeros(M * int(boff[-1]), dtype=torch.int32, device=dev), summary=torch.zeros(nfr * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
 torch.cuda.synchronize(dev)
 from lidar_object_detection_amd import _build  # noqa: E402
-with LpfContext(0, library=_build.LAB_LIB if geometry else None) as ctx:
+clock = bool(os.environ.get("ROLE_CLOCK"))          # lab build: per role of the step launches, block times (fused modes)
+with LpfContext(0, library=os.environ.get("PROBE_LIBRARY") or (_build.LAB_LIB if (geometry or clock) else None)) as ctx:
     if geometry:
         ctx.set_geometry(geometry)
     ctx.set_pipelined(False if mode == "serial" else mode)
     ctx.set_camera(T, K, W, H, 0.0, 50.0)
-    d_rects = torch.from_numpy(LpfContext.mask_rects(np.stack([f["masks"] for f in batch]))).to(dev) if lab == "rects" else None     # the masks' 2D rectangles (lpf_set_mask_rects)
+    d_rects = torch.from_numpy(LpfContext.mask_rects(np.stack([f["masks"] for f in batch]))).to(dev) if (lab == "rects" or os.environ.get("PROBE_RECTS")) else None     # the masks' 2D rectangles (lpf_set_mask_rects)
+    if d_rects is not None and os.environ.get("PROBE_EMPTY_RECTS"):      # experiment: every rectangle empty -- the tiles test them, nothing is ever inside
+        d_rects.zero_()
     fn = ctx.make_device_step(d_pts, off, masks_u8=None if lab == "nomasks" else d_masks, lend=True, boxes_cam0=None if lab == "noboxes" else d_cam0, mask_rects=d_rects,
                               box_off=boff, T_cam_to_velo=Tcv, inst_cap=cap, **o)
     for _ in range(5):
@@ -60,5 +68,11 @@ with LpfContext(0, library=_build.LAB_LIB if geometry else None) as ctx:
         fn()
     ctx.sync()
     print("%s %s %s frames=%d points=%d: %.1f us per step" % (mode, lab or "all", geometry, nfr, ntot, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
+    if clock and mode != "serial":
+        ctx.role_clock(reset=True)
+        for _ in range(reps):
+            fn()
+        for role, r in ctx.role_clock(reset=True).items():
+            print("  %-20s %7d blocks per launch, span %7.2f us, mean block %6.2f us, longest block %6.2f us" % (role, r["blocks"] // reps, r["span_us"] / 1.0, r["mean_us"], r["longest_us"]))
     sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
     print("valid %d masked %d list entries %d" % (sm["n_valid"].sum(), sm["n_labelled"].sum(), sm["inst_count"].sum()))
