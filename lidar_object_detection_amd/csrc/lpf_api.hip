@@ -1114,7 +1114,8 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.pt_off = frame_off[f];
         fr.N = (int)(frame_off[f + 1] - frame_off[f]);
         fr.seg_off = nseg_total;
-        fr.nseg = (int)((fr.N + seg_pts - 1) / seg_pts);
+        fr.shift = (int)(frame_off[f] & 63);               // the frame's rows start at the 64-point boundary below its first point (LpfFrame)
+        fr.nseg = fr.N ? (int)((fr.N + fr.shift + seg_pts - 1) / seg_pts) : 0;
         nseg_total += fr.nseg;
         fr.box_off = BX.F ? BX.box_off[f] : 0;
         fr.B = BX.F ? BX.box_off[f + 1] - BX.box_off[f] : 0;
@@ -1123,7 +1124,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         fr.cand_off = BX.F ? BX.cand_off[f] : 0;
         fr.cand_words = (fr.B + 63) / 64;
         fr.grp_off = ngrp_total;
-        fr.pad3 = 0; fr.pad4 = 0;
+        fr.pad4 = 0;
         const int ngrp = (fr.nseg + LPF_GROUP_SEGS - 1) / LPF_GROUP_SEGS;
         ngrp_total += ngrp;
         if (ngrp > max_ngrp) max_ngrp = ngrp;

@@ -43,7 +43,12 @@ struct LpfFrame {                // one per frame, device + host copy
     long long cand_off;          // first word of the frame's candidate-box grids
     int cand_words;              // grids of the frame: one per 64 boxes = ceil(B / 64)
     int grp_off;                 // first group (of LPF_GROUP_SEGS segments) of the frame
-    int pad3, pad4;
+    int shift;                   // pt_off & 63: the frame's ballot rows start at the 64-point boundary at or below its first point, so that
+                                 // every wave's loads and stores are whole 64-byte lines whatever the frame's place in the batch (a batch of
+                                 // real scans: frames of ~116 k points, none a multiple of 64 -- every 512-byte store of a wave straddled
+                                 // a ninth line, every label store a fifth: +9 % HBM requests, PMC).  Row r, lane l is frame point
+                                 // 64 r + l - shift; the first `shift` lanes of row 0 are dead.
+    int pad4;
 };
 
 struct LpfParams {
@@ -140,7 +145,7 @@ __device__ __forceinline__ LpfFrame lpf_frame_record(const LpfFrame &by_value, c
         const LpfFrame t = table[lpf_uni(idx)];
         fr.pt_off = lpf_uni64(t.pt_off); fr.inst_base = lpf_uni64(t.inst_base); fr.N = lpf_uni(t.N); fr.seg_off = lpf_uni(t.seg_off);
         fr.nseg = lpf_uni(t.nseg); fr.box_off = lpf_uni(t.box_off); fr.B = lpf_uni(t.B); fr.pad = lpf_uni(t.pad);
-        fr.cand_off = lpf_uni64(t.cand_off); fr.cand_words = lpf_uni(t.cand_words); fr.grp_off = lpf_uni(t.grp_off);
+        fr.cand_off = lpf_uni64(t.cand_off); fr.cand_words = lpf_uni(t.cand_words); fr.grp_off = lpf_uni(t.grp_off); fr.shift = lpf_uni(t.shift);
     }
     return fr;
 }
@@ -316,11 +321,14 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
     LpfFrame fr = P.frame0;
     if (P.F > 1) fr = P.segs[__builtin_amdgcn_readfirstlane(sid)];        // wave-uniform: scalar loads, no search
     const int f = fr.pad;
+    // (from here on "point" indices are positions in the frame's rows: frame point + fr.shift, see LpfFrame)
+    const int sh = fr.shift;
+    const long long pbase = fr.pt_off - sh;                              // the 64-point boundary the frame's rows start at
     const int seg_start = (sid - fr.seg_off) * P.seg_pts;
-    const int seg_end = min(seg_start + P.seg_pts, fr.N);
+    const int seg_end = min(seg_start + P.seg_pts, fr.N + sh);
     const int c = seg_start + (lb - sid * tiles_per_seg) * TILE;       // first point of the tile
     if (c >= seg_end) return;                                            // padding tile of a short segment
-    const float4 *__restrict__ pts = P.pts + fr.pt_off;
+    const float4 *__restrict__ pts = P.pts + pbase;
     typedef LpfLabelSrc<LT> Src;
     const typename Src::elem *__restrict__ limg =
         (P.label_img && P.M > 0) ? static_cast<const typename Src::elem *>(P.label_img) + (size_t)f * Src::frame_stride(P) : nullptr;
@@ -357,17 +365,18 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
         // has been issued; RECT tiles know a row's bits at once and keep nothing per row (no lab[] / valid[]: registers).
         auto consume = [&](const int r, uint32_t l, const bool okr) {
             const int idx = wbase + r * 64;
-            if (idx < seg_end && P.label_bits && !(FL & LPF_F_LAB_NOSTORE)) {
-                if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + fr.pt_off + idx);
-                else P.label_bits[fr.pt_off + idx] = l;
+            if (idx >= sh && idx < seg_end && P.label_bits && !(FL & LPF_F_LAB_NOSTORE)) {
+                if (FL & LPF_F_NTSTORE) __builtin_nontemporal_store(l, P.label_bits + pbase + idx);
+                else P.label_bits[pbase + idx] = l;
             }
             const unsigned long long vb = __ballot(okr);
             const unsigned long long mb = __ballot(l != 0);
             if (lane == r) { myv = vb; mym = mb; }
             // the wave's masked points {x, y, z, label}, compacted in point order at the wave's own
             // first slots: the tail reads them back in runs instead of gathering from the cloud
+            // (behind the dead lanes of the frame's first wave: the slots below the frame's first point are the previous frame's)
             if (l && P.mlist && !(FL & LPF_F_LAB_NOSTORE))
-                P.mlist[fr.pt_off + (wbase - lane) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
+                P.mlist[pbase + (wbase - lane) + ((wbase - lane) == 0 ? sh : 0) + nmask_w + __popcll(mb & ((1ull << lane) - 1ull))] =
                     make_float4(p[r].x, p[r].y, p[r].z, __uint_as_float(l));
             nvalid_w += __popcll(vb);
             nmask_w += __popcll(mb);
@@ -380,7 +389,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int idx = wbase + r * 64;
-            const bool live = idx < seg_end;
+            const bool live = idx >= sh && idx < seg_end;
             if (FL & LPF_F_X4) asm volatile("" ::"v"(p[r].w));
             double uf, vf, d, ru, rv;
             if (FL & LPF_F_LAB_NOMATH) {
@@ -407,7 +416,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
                 if (ok && limg) lab[r] = Src::get(limg, P, vi * P.W + ui);
             }
             if (live && !(FL & LPF_F_LAB_NOSTORE)) {
-                const long long g = fr.pt_off + idx;
+                const long long g = pbase + idx;
                 if (P.uv) {
                     if (FL & LPF_F_NTSTORE) {
                         typedef int i2v __attribute__((ext_vector_type(2)));
@@ -751,8 +760,9 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
     }
     unsigned bef, tot;
     lpf_list_prefix<PRE, STEP>(P, fr, sid, bef, tot);
+    const int sh = fr.shift;                               // (row positions are frame points + shift: LpfFrame)
     const int seg_start = k * P.seg_pts;
-    const int seg_end = min(seg_start + P.seg_pts, fr.N);
+    const int seg_end = min(seg_start + P.seg_pts, fr.N + sh);
     const int nrows = (seg_end - seg_start + 63) >> 6;
     if (lane >= nrows) { vb = 0; mb = 0; }                 // rows K1 never wrote
     const unsigned cv = __popcll(vb), cm = __popcll(mb);
@@ -772,7 +782,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
     //      lists); dense one: row after row, a row's entries are one contiguous run already. ---------------------------
     if (P.valid_idx && nv) {
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
-        const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        const long long o = fr.pt_off + run_v, g0 = fr.pt_off - sh + seg_start;
         // run_v comes from counters in memory: whatever they hold, a store never leaves the frame's own N slots (with sound
         // counters run_v + nv <= N always; see DESIGN.md section 9 for the fault this guard is the answer to)
         const long long room = (long long)fr.N - run_v;
@@ -781,7 +791,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
                 const unsigned long long rv = lpf_rl64(vb, r);                      // wave-uniform
                 const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
                 if (((rv >> lane) & 1ull) && pos < room) {
-                    dst[pos] = (long long)(seg_start + r * 64 + lane);
+                    dst[pos] = (long long)(seg_start + r * 64 + lane - sh);
                     if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
                     if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
                 }
@@ -790,7 +800,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
             lpf_bits_to_list(vb, vbase, lane, lst);
             __builtin_amdgcn_wave_barrier();
             for (unsigned e = lane; e < nv && (long long)e < room; e += 64) {
-                const int pt = seg_start + (int)lst[e];
+                const int pt = seg_start + (int)lst[e] - sh;
                 dst[e] = (long long)pt;
                 if (P.uv_valid) P.uv_valid[o + e] = P.uv[fr.pt_off + pt];
                 if (P.label_valid) P.label_valid[o + e] = P.label_bits[fr.pt_off + pt];
@@ -804,9 +814,10 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
     // K1 left each of its waves' masked points {x, y, z, label} compacted at the wave's first slot, in
     // the same order as the set bits of the masked ballots: entry e of the segment, found in
     // row r, is entry e - mbase[first row of r's K1 wave] of that wave.
-    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+    const float4 *__restrict__ mseg = P.mlist + (fr.pt_off - sh) + seg_start;
     const int rows_per_wave = P.tile_pts >> 8;             // K1 tile = 4 waves of tile_pts/4 points
     const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
+    const int dead0 = (seg_start == 0) ? sh : 0;           // the frame's first K1 wave keeps its entries behind its dead lanes
 
     for (int r0 = 0; r0 < nrows;) {                        // passes of at most LPF_LIST_CAP entries (one, except on very dense segments)
         const unsigned start = lpf_rl(mbase, r0);
@@ -838,13 +849,13 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
                     const int first_row = (int)((li >> 6) >> rpw_shift) << rpw_shift;
                     const unsigned wb = (unsigned)__shfl((int)mbase, first_row);        // all lanes take part
                     li4[q] = li;                           // (only the label bits of the hand-off entry are needed here)
-                    if (act) lab4[q] = __float_as_uint(mseg[first_row * 64 + (int)(start + e - wb)].w);
+                    if (act) lab4[q] = __float_as_uint(mseg[first_row * 64 + (first_row == 0 ? dead0 : 0) + (int)(start + e - wb)].w);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {              // split by instance; ballot order == ascending point index
                     if (e0 + 64u * q >= cnt) continue;
                     const unsigned lab = lab4[q];
-                    const long long idx = (long long)(seg_start + (int)li4[q]);
+                    const long long idx = (long long)(seg_start + (int)li4[q] - sh);
                     unsigned any = lpf_wave_or(lab);
                     while (any) {
                         const int m = __ffs(any) - 1;
@@ -883,8 +894,9 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
         vb = P.vbal[(size_t)sid * RPS + lane];
         mb = P.mbal[(size_t)sid * RPS + lane];
     }
+    const int sh = fr.shift;                               // (row positions are frame points + shift: LpfFrame)
     const int seg_start = k * LPF_SEG_SMALL;
-    const int seg_end = min(seg_start + LPF_SEG_SMALL, fr.N);
+    const int seg_end = min(seg_start + LPF_SEG_SMALL, fr.N + sh);
     const int nrows = (seg_end - seg_start + 63) >> 6;
     if (lane >= nrows) { vb = 0; mb = 0; }                 // rows K1 never wrote
     const unsigned cv = __popcll(vb), cm = __popcll(mb);
@@ -901,7 +913,7 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
     if (want_inst) {
         // K1 left each of its waves' masked points compacted at the wave's first slot, in ballot order: the masked point of
         // (row r, lane l) is entry mbase[r] + popc(bits below l) of the segment, entry - mbase[first row of r's K1 wave] of that wave
-        const float4 *__restrict__ mseg = P.mlist + fr.pt_off + seg_start;
+        const float4 *__restrict__ mseg = P.mlist + (fr.pt_off - sh) + seg_start;
         const int rows_per_wave = P.tile_pts >> 8;
         const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
 #pragma unroll
@@ -910,7 +922,8 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
             labr[r] = 0u;
             if (rm) {
                 const int first_row = (r >> rpw_shift) << rpw_shift;
-                const unsigned at = lpf_rl(mbase, r) - lpf_rl(mbase, first_row) + __popcll(rm & lt);
+                const unsigned at = lpf_rl(mbase, r) - lpf_rl(mbase, first_row) + __popcll(rm & lt) +
+                                    ((first_row == 0 && seg_start == 0) ? (unsigned)sh : 0u);     // (behind the dead lanes of the frame's first K1 wave)
                 if ((rm >> lane) & 1ull) labr[r] = __float_as_uint(mseg[first_row * 64 + (int)at].w);
             }
         }
@@ -920,7 +933,7 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
     const long long run_v = (long long)lpf_rl(bef, 0);     // valid points of the frame before this segment
     if (P.valid_idx && nv) {
         long long *__restrict__ dst = P.valid_idx + fr.pt_off + run_v;
-        const long long o = fr.pt_off + run_v, g0 = fr.pt_off + seg_start;
+        const long long o = fr.pt_off + run_v, g0 = fr.pt_off - sh + seg_start;
         // run_v comes from counters in memory: whatever they hold, a store never leaves the frame's own N slots (with sound
         // counters run_v + nv <= N always; see DESIGN.md section 9 for the fault this guard is the answer to)
         const long long room = (long long)fr.N - run_v;
@@ -929,7 +942,7 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
             if (rv == 0ull) continue;
             const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
             if (((rv >> lane) & 1ull) && pos < room) {
-                dst[pos] = (long long)(seg_start + r * 64 + lane);
+                dst[pos] = (long long)(seg_start + r * 64 + lane - sh);
                 if (P.uv_valid) P.uv_valid[o + pos] = P.uv[g0 + r * 64 + lane];
                 if (P.label_valid) P.label_valid[o + pos] = P.label_bits[g0 + r * 64 + lane];
             }
@@ -941,7 +954,7 @@ __device__ __forceinline__ void lpf_lists_wave_small(const LpfParams &P, const L
     for (int r = 0; r < RPS; ++r) {
         const unsigned lab = labr[r];
         unsigned any = lpf_wave_or(lab);
-        const long long idx = (long long)(seg_start + r * 64 + lane);
+        const long long idx = (long long)(seg_start + r * 64 + lane - sh);
         while (any) {
             const int m = __ffs(any) - 1;
             any &= any - 1u;
@@ -996,7 +1009,7 @@ __device__ __forceinline__ unsigned lpf_count_rows(const LpfParams &P, const Lpf
     unsigned long long mb = 0;
     if (lane < rps) mb = P.mbal[(size_t)sid * rps + lane];
     const int seg_start = (sid - fr.seg_off) * P.seg_pts;
-    const int nrows = (min(seg_start + P.seg_pts, fr.N) - seg_start + 63) >> 6;
+    const int nrows = (min(seg_start + P.seg_pts, fr.N + fr.shift) - seg_start + 63) >> 6;       // (row positions: frame points + shift)
     if (lane >= nrows) mb = 0;                             // rows K1 never wrote
     const unsigned cm = __popcll(mb);
     im = cm;
@@ -1017,7 +1030,7 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
 {
     const int lane = lpf_lane();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const float4 *__restrict__ mseg = P.mlist + fr.pt_off + (size_t)(sid - fr.seg_off) * P.seg_pts;
+    const float4 *__restrict__ mseg = P.mlist + (fr.pt_off - fr.shift) + (size_t)(sid - fr.seg_off) * P.seg_pts;
     const int rows_per_wave = P.tile_pts >> 8;
     const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
     auto exact = [&](int count) {
@@ -1052,7 +1065,7 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
     const int first_row = (row >> rpw_shift) << rpw_shift;
     const unsigned wb = (unsigned)__shfl((int)mbase, first_row);
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) p = mseg[first_row * 64 + (int)(e - wb)];
+    if (act) p = mseg[first_row * 64 + ((first_row == 0 && sid == fr.seg_off) ? fr.shift : 0) + (int)(e - wb)];    // (behind the dead lanes of the frame's first K1 wave)
     __builtin_amdgcn_wave_barrier();
     s_pt[lane] = p;                                         // .w carries the label bits (0 for idle lanes)
     __builtin_amdgcn_wave_barrier();
