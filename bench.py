@@ -424,12 +424,13 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H, use_rects=True):
                 sm = np.frombuffer(dbs[0]["o"]["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
                 nv, nl = int(sm["n_valid"].sum()), int(sm["inst_count"].sum())
                 br = 1e-3 * ms / max(cnt, 1)
-                # itemised: + the masks read and the label images written by the riding pack (5 masks x 1408 x 376 bytes per frame:
-                # 2.6 MB of masks next to 3.2 MB of strict point traffic per frame), the label look-ups, valid_idx, the lists
+                # itemised.  With the masks' rectangles the tiles read the masks themselves inside the rectangles: no pack, no label image --
+                # per valid point a 4-byte look-up in the frame's candidate grid, per list entry a mask byte, + valid_idx and the lists.
+                # Without them: + the masks read and the label images written by the riding pack (5 masks x 1408 x 376 bytes per frame:
+                # 2.6 MB of masks next to 3.2 MB of strict point traffic per frame) and the label look-ups.
                 rect_bytes = int(sum(int(((r[:, :, 2] - r[:, :, 0]) * (r[:, :, 3] - r[:, :, 1])).sum()) for r in [dbs[0]["rects"].cpu().numpy().astype(np.int64)]))
-                mask_read = rect_bytes if use_rects else nfr * dbs[0]["M"] * Wg * Hg       # (with the rectangles only what lies inside them is read)
-                item = ALGO_BYTES_PER_POINT * ntot_r + mask_read + nfr * Wg * Hg + 12 * nv + 8 * nl
                 item_plain = ALGO_BYTES_PER_POINT * ntot_r + nfr * (dbs[0]["M"] + 1) * Wg * Hg + 12 * nv + 8 * nl
+                item = (ALGO_BYTES_PER_POINT * ntot_r + 12 * nv + 9 * nl) if use_rects else item_plain
                 out["real_scans_at_headline_size"] = {
                     "frames_per_step": nfr, "points_per_step": ntot_r, "valid_fraction": nv / ntot_r, "masked_list_entries_per_step": nl,
                     "boxes_given_per_step": int(dbs[0]["boff"][-1]), "boxes_change_every_step": True, "mode": "fused-pack",
@@ -443,11 +444,15 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H, use_rects=True):
                     "mask_bytes_inside_the_rectangles_per_step": rect_bytes,
                     "us_per_step_without_mask_rectangles": None if dt_plain is None else 1e6 * dt_plain,
                     "itemised_frac_of_hbm_peak_without_mask_rectangles": None if dt_plain is None else item_plain / dt_plain / 1e9 / HBM_PEAK_GBS,
-                    "why_below_the_synthetic_headline": "a real frame brings 2.6 MB of masks for 3.2 MB of strict point traffic (the synthetic "
-                                                        "cloud: 4.2 MB for 56 MB; with the masks' 2D rectangles only the 42 KB inside them are read, the "
-                                                        "0.5 MB label image is still written), its tail works on 5 x the valid and masked points per input point, "
-                                                        "and half of these frames carry 186 / 314 annotated boxes; per-kernel split: "
-                                                        "profiles/r03_real146_kernel_stats_*.csv, DESIGN.md section 8",
+                    "masks_with_rectangles": "the tiles read the lent masks themselves inside their rectangles (candidate grid + exact test): "
+                                             "no pack, no label image",
+                    "why_below_the_synthetic_headline": "not bytes any more (PMC: 580 MB per launch for 474 strict, 4.3 TB/s of a 5.9 TB/s copy ceiling; "
+                                                        "round 3: 743 MB) but the tail riding in the launch: a fifth of a real scan's points are valid "
+                                                        "and 1.8 % lie on a car (the synthetic cloud: 4.7 % and 0.6 %), half of these frames carry 186 / 314 "
+                                                        "annotated boxes, and the lists / box counts of the run before take block slots from the tiles "
+                                                        "(in order: tiles + box job 102, tail 53, summaries 7 us); without the rectangles a real frame "
+                                                        "brings 2.6 MB of masks for 3.2 MB of strict point traffic; per-kernel split and counters: "
+                                                        "profiles/r04_real146_kernel_stats_*.csv, profiles/r04_pmc_real146.json, DESIGN.md section 8",
                     "host_waits_and_drains_in_the_pipelined_stream": [st["host_waits"] - 2, st["drains"] - 2],
                     "data": "KITTI-360 sample frames 100, 1461, 2098, 2449 in turn (tests/golden: the reference's inputs), real scan order",
                     "checked": "count_mb (kept boxes; dropped boxes zero), n_valid, inst_count of all 146 frames of both batches == the golden vectors (reference functions)"}

@@ -43,7 +43,7 @@ extern "C" {
                                          lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
                                          section 8); lpf_set_geometry only in lab builds (-DLPF_LAB)
                                       6: lpf_set_mask_rects, lpf_resize_masks_u8 (added; nothing else changed)
-                                      7: lpf_build_id, lpf_host_alloc / lpf_host_free, lpf_run_frame (added; nothing else changed) */
+                                      7: lpf_build_id, lpf_host_alloc / lpf_host_free, lpf_run_frame, lpf_erode_masks_u8 (added; nothing else changed) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -239,6 +239,28 @@ int lpf_run(lpf_ctx *ctx, const float *pts, int64_t N, int pts_on_device, const 
 int lpf_run_batch(lpf_ctx *ctx, const float *pts, const int64_t *frame_off, int F,
                   int pts_on_device, const lpf_outputs *out);
 
+/* One frame of a stream in ONE call (one FFI crossing instead of four): what a frame of the reference's loop brings -- its scan, its
+ * detection masks with their 2D boxes, its annotated 3D boxes (V3:545-562) -- and where its results go.  Exactly the sequence
+ *   lpf_set_mask_rects(ctx, mask_rects, 1, 1, n_masks)                  if mask_rects
+ *   lpf_set_masks_u8(ctx, masks, 1, n_masks, 0, 2)                      if masks        (lent: on_device = 2)
+ *   lpf_set_boxes_cam0(ctx, corners_cam0, 2, {0, n_boxes}, 1, T_cam_to_velo, filter_visible, oriented, 0, 0, 0, 0)   if corners_cam0
+ *   lpf_run(ctx, pts, n_points, 1, &out)
+ * with the same meaning, ownership and error behaviour; a NULL masks / corners_cam0 leaves the masks / boxes in force as they are.
+ * Every pointer except T_cam_to_velo is device memory; out.on_device must be 1.  For launch-bound frame loops: in a software-
+ * pipelined stream of single real frames the three calls took the host 7.9 us per frame against 9.2 us on the GPU. */
+typedef struct lpf_frame_job {
+    const float   *pts;            /* [n_points][4] */
+    int64_t        n_points;
+    const uint8_t *masks;          /* [n_masks][H][W], lent; or NULL */
+    const int32_t *mask_rects;     /* [n_masks][4] {x0, y0, x1, y1}, lent like the masks; or NULL */
+    const double  *corners_cam0;   /* [n_boxes][8][3], lent; or NULL */
+    const double  *T_cam_to_velo;  /* host memory, row-major 4x4 (with corners_cam0) */
+    int32_t        n_masks, n_boxes;
+    int32_t        filter_visible, oriented;
+    lpf_outputs    out;
+} lpf_frame_job;
+int lpf_run_frame(lpf_ctx *ctx, const lpf_frame_job *job);
+
 /* ---- box membership as a stand-alone operator -------------------------------------------
  * inside[b*k + i] = 1 if point i lies in box b, else 0: the boolean arrays the reference's
  * oriented_point_in_bbox (V3:167-208, oriented = 1) and point_in_bbox (V3:143-164, oriented = 0)
@@ -263,6 +285,13 @@ int lpf_depth_image(lpf_ctx *ctx, const float *pts, int64_t N, int on_device, do
  * decimation, which OpenCV hands to INTER_AREA, is refused.  on_device: both pointers in host (0) or device (1) memory; device
  * callers: in stream order.  Not capturable. */
 int lpf_resize_masks_u8(lpf_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst, int on_device);
+
+/* cv2.erode(plane, cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (3, 3)), iterations=iters) on n planes [h][w] of 8-bit VALUES, at the
+ * planes' own size (V3:83-90): the minimum over the plus-shaped neighbourhood, the image border left out.  For masks that do not
+ * arrive at camera size the reference erodes first and resizes afterwards (V3:82-97, then V3:222): this call, then
+ * lpf_resize_masks_u8.  (Masks at camera size are eroded inside lpf_set_masks_*, on the packed label image.)  src != dst; host or
+ * device pointers per on_device, device callers in stream order.  Pinned by construction only, like lpf_set_masks_*'s erosion. */
+int lpf_erode_masks_u8(lpf_ctx *ctx, const uint8_t *src, int n, int h, int w, int iters, uint8_t *dst, int on_device);
 
 /* ---- box preparation on the GPU --------------------------------------------------------------
  * For nbox annotated boxes given by their 8 corners in the cam-0 frame (f64 [nbox][8][3], the

@@ -47,6 +47,13 @@ class Outputs(ctypes.Structure):
                 ("uv_valid", _P), ("label_valid", _P)]
 
 
+class FrameJob(ctypes.Structure):
+    """lpf_frame_job (include/lpf.h): one frame of a stream -- scan, masks + rectangles, cam-0 box corners, outputs -- for lpf_run_frame"""
+    _fields_ = [("pts", _P), ("n_points", _I64), ("masks", _P), ("mask_rects", _P), ("corners_cam0", _P), ("T_cam_to_velo", _P),
+                ("n_masks", ctypes.c_int32), ("n_boxes", ctypes.c_int32), ("filter_visible", ctypes.c_int32), ("oriented", ctypes.c_int32),
+                ("out", Outputs)]
+
+
 _libs = {}
 
 
@@ -123,6 +130,7 @@ def load(path=None):
     lib.lpf_set_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_mask_rects.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_resize_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
+    lib.lpf_erode_masks_u8.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
     lib.lpf_set_masks_f32.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_set_label_image.argtypes = [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.lpf_get_label_image.argtypes = [_P, _P, ctypes.c_int]
@@ -131,6 +139,7 @@ def load(path=None):
     lib.lpf_set_boxes_cam0.argtypes = [_P, _P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]
     lib.lpf_run.argtypes = [_P, _P, _I64, ctypes.c_int, ctypes.POINTER(Outputs)]
     lib.lpf_run_batch.argtypes = [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Outputs)]
+    lib.lpf_run_frame.argtypes = [_P, ctypes.POINTER(FrameJob)]
     lib.lpf_points_in_boxes.argtypes = [_P, _P, _I64, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int]
     lib.lpf_depth_image.argtypes = [_P, _P, _I64, ctypes.c_int, _P, _P]
     lib.lpf_prepare_boxes.argtypes = [_P, _P, ctypes.c_int, _P, _P, _P, _P, _P]
@@ -157,8 +166,8 @@ EXPORTED = ("lpf_abi_version", "lpf_build_id", "lpf_host_alloc", "lpf_host_free"
             "lpf_release_to_stream", "lpf_sync",
             "lpf_set_pipelined", "lpf_allreduce_metrics",
             "lpf_set_camera", "lpf_set_masks_u8", "lpf_set_masks_f32", "lpf_set_mask_rects", "lpf_set_label_image",
-            "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch",
-            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_resize_masks_u8", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
+            "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch", "lpf_run_frame",
+            "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_resize_masks_u8", "lpf_erode_masks_u8", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
             "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
 
@@ -460,6 +469,28 @@ class LpfContext:
         self._check(self._lib.lpf_resize_masks_u8(self._h, a.ctypes.data if n else None, n, shape[-2], shape[-1], out.ctypes.data if n else None, 0))
         return out
 
+    def erode_masks(self, masks, iterations=1):
+        """cv2.erode(plane, MORPH_ELLIPSE 3x3, iterations) on uint8 VALUES [..., h, w] at the planes' own size (V3:83-90, for masks that
+        are eroded before they are resized): NumPy in -> NumPy out, uint8 torch GPU tensor in -> tensor out (ordered with torch's
+        current stream on both sides)."""
+        if _is_torch(masks):
+            import torch
+            if str(masks.dtype) != "torch.uint8" or not masks.is_contiguous():
+                raise ValueError("device masks must be a contiguous uint8 tensor")
+            shape = tuple(masks.shape)
+            out = torch.empty_like(masks)
+            n = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+            ts = torch.cuda.current_stream(masks.device).cuda_stream
+            self.wait_for_stream(ts)
+            self._check(self._lib.lpf_erode_masks_u8(self._h, _dev_ptr(masks) if n else None, n, shape[-2], shape[-1], int(iterations), _dev_ptr(out) if n else None, 1))
+            self.release_to_stream(ts)
+            return out
+        a = np.ascontiguousarray(np.asarray(masks), dtype=np.uint8)
+        out = np.empty_like(a)
+        n = int(np.prod(a.shape[:-2], dtype=np.int64)) if a.ndim > 2 else 1
+        self._check(self._lib.lpf_erode_masks_u8(self._h, a.ctypes.data if n else None, n, a.shape[-2], a.shape[-1], int(iterations), out.ctypes.data if n else None, 0))
+        return out
+
     def set_mask_rects(self, rects):
         """Hint for the NEXT set_masks call: rects int32 [M,4] or [F,M,4] = (x0, y0, x1, y1), half open, pixels -- mask m of frame f is
         zero outside its rectangle (a detector's masks come cropped to their 2D boxes).  Where uint8 masks are packed as they are the
@@ -693,10 +724,15 @@ class LpfContext:
         pinned=True: the result arrays are views into page-locked buffers the context owns and reuses -- valid until the next
         run on this context (copy what must live longer); the frame loops use it."""
         scan = frames[0] if (len(frames) == 1 and isinstance(frames[0], Scan)) else None
+        dev_pts = frames[0] if (len(frames) == 1 and _is_torch(frames[0])) else None
         if scan is not None:                     # points already in HBM (ScanReader): no host staging
             frames = [scan.points]
-        elif any(isinstance(p, Scan) for p in frames):
-            raise ValueError("a Scan from a ScanReader is processed on its own (one frame per run)")
+        elif dev_pts is not None:                # ... or a float32 [N,4] torch tensor on the GPU (ordered with torch's current stream)
+            if dev_pts.ndim != 2 or dev_pts.shape[1] != 4:
+                raise ValueError("device points must be a float32 tensor [N,4]")
+            frames = [np.empty((int(dev_pts.shape[0]), 4), np.float32)]      # (only its shape is used below)
+        elif any(isinstance(p, Scan) or _is_torch(p) for p in frames):
+            raise ValueError("a Scan from a ScanReader / a GPU tensor of points is processed on its own (one frame per run)")
         frames = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 4) for p in frames]
         F = len(frames)
         off = np.zeros(F + 1, np.int64)
@@ -707,6 +743,10 @@ class LpfContext:
         if scan is not None:
             scan._check_live()
             pts_ptr, pts_dev = (scan.dev_ptr if n else None), 1
+        elif dev_pts is not None:
+            import torch
+            self.wait_for_stream(torch.cuda.current_stream(dev_pts.device).cuda_stream)      # the tensor was produced on torch's stream
+            pts_ptr, pts_dev = (_dev_ptr(dev_pts, "float32") if n else None), 1
         M = self.M if self.F_masks else 0
         Btot = int(self.box_off[-1]) if self.box_off is not None else 0
         if inst_cap is None:
@@ -787,6 +827,52 @@ class LpfContext:
         o.uv_valid, o.label_valid = _dev_ptr(uv_valid, "int32"), _dev_ptr(label_valid)
         self._check(self._lib.lpf_run_batch(self._h, _dev_ptr(pts, "float32"), off.ctypes.data, F, 1,
                                             ctypes.byref(o)))
+
+    def make_frame_step(self, pts, masks_u8=None, mask_rects=None, boxes_cam0=None, T_cam_to_velo=None, filter_visible=True, oriented=True, **outs):
+        """Pre-marshal ONE frame of a stream -- scan, lent uint8 masks [M,H,W] (+ their rectangles [M,4]), lent cam-0 box corners
+        [B,8,3], output tensors as in make_device_step -- into an lpf_frame_job and return a zero-argument callable that makes the one
+        C call (lpf_run_frame): masks, rectangles, boxes and the run in a single FFI crossing.  Lent tensors stay unchanged until the
+        frame's results are complete (pipelined modes: two launches later)."""
+        j = FrameJob()
+        n = int(pts.shape[0])
+        j.pts, j.n_points = _dev_ptr(pts, "float32"), n
+        keep = [pts, outs]
+        if masks_u8 is not None:
+            shape = tuple(masks_u8.shape)
+            if len(shape) != 3 or shape[1:] != (self.H, self.W) or str(masks_u8.dtype) != "torch.uint8":
+                raise ValueError("masks_u8 must be a torch.uint8 GPU tensor [M,H,W]")
+            j.masks, j.n_masks = _dev_ptr(masks_u8), shape[0]
+            self.F_masks, self.M = 1, shape[0]
+            keep.append(masks_u8)
+            if mask_rects is not None:
+                if tuple(mask_rects.shape) != (shape[0], 4) or str(mask_rects.dtype) != "torch.int32" or not mask_rects.is_contiguous():
+                    raise ValueError("mask_rects must be a contiguous torch.int32 GPU tensor [M,4]")
+                j.mask_rects = _dev_ptr(mask_rects)
+                keep.append(mask_rects)
+        if boxes_cam0 is not None:
+            Tcv = np.ascontiguousarray(T_cam_to_velo, dtype=np.float64).reshape(16)
+            j.corners_cam0, j.n_boxes, j.T_cam_to_velo = _dev_ptr(boxes_cam0, "float64") if boxes_cam0.shape[0] else None, int(boxes_cam0.shape[0]), Tcv.ctypes.data
+            j.filter_visible, j.oriented = int(bool(filter_visible)), int(bool(oriented))
+            self.box_off = np.array([0, int(boxes_cam0.shape[0])], np.int32)
+            keep += [boxes_cam0, Tcv]
+        o = j.out
+        o.on_device = 1
+        o.uv = _dev_ptr(outs.get("uv"), "int32")
+        o.label_bits = _dev_ptr(outs.get("label_bits"))
+        o.depth, o.u_f, o.v_f = (_dev_ptr(outs.get("depth"), "float64"), _dev_ptr(outs.get("u_f"), "float64"), _dev_ptr(outs.get("v_f"), "float64"))
+        o.valid_idx = _dev_ptr(outs.get("valid_idx"), "int64")
+        o.inst_idx = _dev_ptr(outs.get("inst_idx"), "int64")
+        o.inst_cap = int(outs.get("inst_cap", 0))
+        o.count_mb = _dev_ptr(outs.get("count_mb"), "int32")
+        o.summary = _dev_ptr(outs.get("summary"))
+        o.uv_valid, o.label_valid = _dev_ptr(outs.get("uv_valid"), "int32"), _dev_ptr(outs.get("label_valid"))
+        run, h, check, ref = self._lib.lpf_run_frame, self._h, self._check, ctypes.byref(j)
+
+        def fn(_keep=(j, keep)):
+            rc = run(h, ref)
+            if rc:
+                check(rc)
+        return fn
 
     def make_device_step(self, pts, frame_off, masks_u8=None, erode_iters=0, lend=False, boxes_cam0=None, box_off=None,
                          T_cam_to_velo=None, filter_visible=True, oriented=True, mask_rects=None, **outs):

@@ -1220,13 +1220,18 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     //  half its image has pixels: a real scan, 110 k points on 530 k pixels, 29.9 -> 24.9 us per 20-frame batch in a pipelined
     //  stream; a synthetic 2 M-point cloud is better off with the pack riding, 21.8 vs 24.2 us)
     const bool sparse_frames = Ntot * 2 <= (int64_t)F * c->W * c->H;
-    // ... and with the masks' rectangles (lpf_set_mask_rects) a launch of ANY size reads the masks inside them: no pack, no label image
-    const bool direct_rect_fused = c->ride.valid && fused && M > 0 && c->ride.rects && ((!c->ride.f32 && c->ride.mode == 0) || (c->ride.f32 && c->ride.mode == 1));
+    // ... and with the masks' rectangles (lpf_set_mask_rects) a launch of sparse frames of ANY size reads the masks inside them: no
+    // pack, no label image (146 real frames per step: 176 -> 134 us).  Dense frames keep the pack: with 2 M points on 530 k pixels and
+    // rectangles that cover a good part of the image every row meets a rectangle, and the exact test of such a row is a dependent round
+    // trip (one 2 M-point cloud with 8 disk masks, tiles 18.5 -> 21 us, pipelined stream 21.4 -> 25.4 us per cloud).
+    const bool direct_rect_fused = c->ride.valid && fused && M > 0 && sparse_frames && c->ride.rects &&
+                                   ((!c->ride.f32 && c->ride.mode == 0) || (c->ride.f32 && c->ride.mode == 1));
     const bool direct_fused = direct_rect_fused || (c->ride.valid && fused && small && sparse_frames && M > 0);
     const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
     if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
-    const bool direct_rect = M > 0 && c->lazy.valid && !fused && c->lazy.rects && ((!c->lazy.f32 && c->lazy.mode == 0) || (c->lazy.f32 && c->lazy.mode == 1));
+    const bool direct_rect = M > 0 && c->lazy.valid && !fused && sparse_frames && c->lazy.rects &&
+                             ((!c->lazy.f32 && c->lazy.mode == 0) || (c->lazy.f32 && c->lazy.mode == 1));
     const bool direct = direct_rect || (M > 0 && c->lazy.valid && small && sparse_frames && !fused);
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
     // The label image lives in the scratch set that was current when the masks were set.  A pipelined run must find it in its
@@ -1546,6 +1551,45 @@ int lpf_resize_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, uin
     return LPF_OK;
 }
 
+// n planes [h][w] of uint8 values, eroded `iters` times with the 3x3 cross at their own size (V3:83-90): see include/lpf.h
+int lpf_erode_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, int iters, uint8_t *dst, int on_device)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (use_device(c)) return LPF_ERR_HIP;
+    if (n < 0 || h <= 0 || w <= 0 || iters < 0 || (n > 0 && (!src || !dst || src == dst)) || (long long)h * w > 0x7fffffffll || (long long)n * h * w > (1ll << 36))
+        return fail(c, LPF_ERR_ARG, "erode_masks: n=%d h=%d w=%d iters=%d src=%p dst=%p (src != dst)", n, h, w, iters, (const void *)src, (void *)dst);
+    if (n == 0) return LPF_OK;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "erode_masks inside a graph capture");
+    int rc;
+    if (anything_owed(c) && (rc = sync_all(c))) return rc;                // (the staging buffer below may be in use by owed runs)
+    const size_t bytes = (size_t)n * h * w;
+    // device callers: dst and one scratch plane set ping-pong; host callers: three staging copies
+    if ((rc = reserve(c, c->resize_buf, on_device ? bytes : 3 * bytes))) return rc;
+    uint8_t *a = on_device ? dst : (uint8_t *)c->resize_buf.p, *b = on_device ? (uint8_t *)c->resize_buf.p : (uint8_t *)c->resize_buf.p + bytes;
+    const uint8_t *cur = src;
+    if (!on_device) {
+        uint8_t *in = (uint8_t *)c->resize_buf.p + 2 * bytes;
+        LPF_HIP(c, hipMemcpyAsync(in, src, bytes, hipMemcpyHostToDevice, c->stream));
+        cur = in;
+    }
+    const long long total = (long long)bytes;
+    const dim3 g((unsigned)((total + LPF_BLOCK - 1) / LPF_BLOCK));
+    // the last iteration must land in `a` (dst for device callers): with an even count the first one goes to b
+    uint8_t *out = (iters % 2 == 1) ? a : b;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(lpf_erode_u8_kernel, g, dim3(LPF_BLOCK), 0, c->stream, cur, out, w, h, total);
+        LPF_HIP(c, hipGetLastError());
+        cur = out;
+        out = (out == a) ? b : a;
+    }
+    if (iters == 0) LPF_HIP(c, hipMemcpyAsync(a, cur, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (!on_device) {
+        LPF_HIP(c, hipMemcpyAsync(dst, a, bytes, hipMemcpyDeviceToHost, c->stream));
+        LPF_HIP(c, host_wait(c));
+    }
+    return LPF_OK;
+}
+
 int lpf_depth_image(lpf_ctx *c, const float *pts, int64_t N, int on_device, double *depth_img, int32_t *winner)
 {
     if (!c) return LPF_ERR_ARG;
@@ -1778,6 +1822,26 @@ int lpf_run(lpf_ctx *c, const float *pts, int64_t N, int pts_on_device, const lp
 {
     const int64_t off[2] = {0, N};
     return lpf_run_batch(c, pts, off, 1, pts_on_device, out);
+}
+
+// one frame of a stream in one call: masks (+ rectangles), boxes, run (include/lpf.h)
+int lpf_run_frame(lpf_ctx *c, const lpf_frame_job *j)
+{
+    if (!c) return LPF_ERR_ARG;
+    if (!j) return fail(c, LPF_ERR_ARG, "lpf_run_frame: job is NULL");
+    if (!j->out.on_device) return fail(c, LPF_ERR_ARG, "lpf_run_frame: device-mode outputs only (out.on_device = 1)");
+    if (j->n_masks < 0 || j->n_boxes < 0) return fail(c, LPF_ERR_ARG, "lpf_run_frame: n_masks=%d n_boxes=%d", j->n_masks, j->n_boxes);
+    int rc;
+    if (j->masks) {
+        if (j->mask_rects && (rc = lpf_set_mask_rects(c, j->mask_rects, 1, 1, j->n_masks))) return rc;
+        if ((rc = lpf_set_masks_u8(c, j->masks, 1, j->n_masks, 0, 2))) return rc;
+    }
+    if (j->corners_cam0) {
+        const int32_t boff[2] = {0, j->n_boxes};
+        if ((rc = lpf_set_boxes_cam0(c, j->corners_cam0, 2, boff, 1, j->T_cam_to_velo, j->filter_visible, j->oriented, nullptr, nullptr, nullptr, nullptr)))
+            return rc;
+    }
+    return lpf_run(c, j->pts, j->n_points, 1, &j->out);
 }
 
 }  // extern "C"

@@ -46,37 +46,56 @@ def _is_device_tensor(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
-def _mask_stack(masks, camera, resize_ctx=None):
-    """[M,H,W] float32/uint8 array from the reference's mask list.  A torch tensor that is already on the GPU --
+def _mask_stack(masks, camera, resize_ctx=None, erode_iters=0, v3_pipeline=False, force_chain=False):
+    """([M,H,W] float32/uint8 array from the reference's mask list, eroded_already).  A torch tensor that is already on the GPU --
     ``result.masks.data`` before the reference's ``.cpu().numpy()`` (V3:72) -- is passed through: the kernels read it where it is.
     Masks that do not arrive at the camera's size (the reference's scripts pass retina_masks=True, V3:64, so theirs do) go through
     ``cv2.resize(mask.astype(np.uint8), (W, H))`` as V3:222 does it -- on the GPU, by ``resize_ctx`` (whose camera must have been
-    set; LpfContext.resize_masks) -- and come back as uint8 [M,H,W], nonzero = the reference's ``> 0.5``."""
-    def resized(m):
+    set; LpfContext.resize_masks) -- and come back as uint8 [M,H,W], nonzero = the reference's ``> 0.5``.  With the V3 erosion block
+    in force (``v3_pipeline`` / ``erode_iters``) such masks take V3's own order: ``(mask * 255).astype(uint8)`` -> ``cv2.erode`` AT THE
+    MASKS' OWN SIZE -> ``/ 255.0`` (V3:82-97), and only then ``astype(uint8)`` + resize (V3:222) -- all on the GPU
+    (LpfContext.erode_masks, then resize_masks); the second value tells the caller that the erosion has been done.  ``force_chain``:
+    masks at camera size take the same explicit chain (a batch is eroded either all inside lpf_set_masks_* or all here)."""
+    def chain(m):
+        """off-size masks -> uint8 [M,H,W] at camera size (device tensor in -> device tensor out)"""
         if resize_ctx is None:
             raise NotImplementedError("masks must already be %dx%d (retina_masks=True, V3:64) in this call" % (camera.height, camera.width))
-        return resize_ctx.resize_masks(m)
+        if not (erode_iters or v3_pipeline):
+            return resize_ctx.resize_masks(m), False
+        dev = _is_device_tensor(m)
+        if dev:
+            import torch
+            f = m.to(torch.float32)
+            u8 = (f * 255).to(torch.uint8) if v3_pipeline else f.to(torch.uint8)       # (mask * 255).astype(np.uint8), V3:85
+            er = resize_ctx.erode_masks(u8.contiguous(), erode_iters)                 # cv2.erode at the masks' own size, V3:86-90
+            back = (er == 255).to(torch.uint8) if v3_pipeline else er                 # / 255.0 (V3:93) then astype(np.uint8) (V3:222): 1 only for 255
+        else:
+            f = np.asarray(m)
+            u8 = (f.astype(np.float32) * 255).astype(np.uint8) if v3_pipeline else f.astype(np.uint8)
+            er = resize_ctx.erode_masks(u8, erode_iters)
+            back = (er.astype(np.float32) / 255.0).astype(np.uint8) if v3_pipeline else er
+        return resize_ctx.resize_masks(back), True
     if _is_device_tensor(masks):
         import torch
         if masks.ndim != 3:
             raise ValueError("device masks must be [M,h,w]")
-        if tuple(masks.shape[1:]) != (camera.height, camera.width):
-            return resized(masks)
+        if tuple(masks.shape[1:]) != (camera.height, camera.width) or (force_chain and masks.shape[0]):
+            return chain(masks)
         if masks.dtype == torch.bool:
             masks = masks.to(torch.uint8)
         elif masks.dtype not in (torch.float32, torch.uint8):
             masks = masks.to(torch.float32)
-        return masks.contiguous()
+        return masks.contiguous(), False
     m = np.asarray(masks)
     if m.size == 0:
-        return np.zeros((0, camera.height, camera.width), np.uint8)
+        return np.zeros((0, camera.height, camera.width), np.uint8), False
     if m.ndim != 3:
         raise ValueError("masks must be [M,h,w]")
-    if m.shape[1:] != (camera.height, camera.width):
-        return resized(m)
+    if m.shape[1:] != (camera.height, camera.width) or force_chain:
+        return chain(m)
     if m.dtype.kind == "f":
-        return np.ascontiguousarray(m, dtype=np.float32)
-    return np.ascontiguousarray(m.astype(np.uint8))
+        return np.ascontiguousarray(m, dtype=np.float32), False
+    return np.ascontiguousarray(m.astype(np.uint8)), False
 
 
 # ---------------------------------------------------------------------------------------
@@ -122,12 +141,14 @@ def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0, keep_all=False):
     corners = np.array([b["corners_cam0"] for b in have], np.float64).reshape(-1, 8, 3)
     vis, cv, bb, fr = ctx.prepare_boxes(corners, np.linalg.inv(TrVeloToCam))
     out = []
+    cv_l, bb_l, fr_l, vis_l = cv.tolist(), bb.tolist(), fr.tolist(), vis.tolist()      # (one conversion each: per box it cost more than the kernels)
     for i, b in enumerate(have):
-        if vis[i] or keep_all:
+        if vis_l[i] or keep_all:
             d = dict(b)
-            d["corners_velo"] = cv[i].tolist()
-            d["_bbox2d"] = bb[i].tolist() if fr[i] > 0 else None
-            d["_front"] = int(fr[i])
+            d["corners_velo"] = cv_l[i]
+            d["_cv"] = cv[i]                                 # the same values as an array (private: spares run_frames the way back from lists)
+            d["_bbox2d"] = bb_l[i] if fr_l[i] > 0 else None
+            d["_front"] = fr_l[i]
             out.append(d)
     return out
 
@@ -137,6 +158,8 @@ def _corners_velo(bboxes_3d):
     pos = [i for i, b in enumerate(bboxes_3d) if "corners_velo" in b]
     if not pos:
         return np.zeros((0, 8, 3)), pos
+    if all("_cv" in bboxes_3d[i] for i in pos):             # boxes that come from prepare_boxes carry their corners as arrays too
+        return np.stack([bboxes_3d[i]["_cv"] for i in pos]).reshape(-1, 8, 3), pos
     return np.array([bboxes_3d[i]["corners_velo"] for i in pos], np.float64).reshape(-1, 8, 3), pos
 
 
@@ -177,7 +200,7 @@ def extract_car_points_by_mask(points_valid, u_valid, v_valid, masks, camera, de
     n = pv.shape[0]
     ctx = get_context(device)
     ctx.set_camera(np.eye(4), np.eye(3), camera.width, camera.height, 0.0, 2.0)
-    stack = _mask_stack(masks, camera, resize_ctx=ctx)       # (V3:222: masks of another size are resized, on the GPU)
+    stack, _ = _mask_stack(masks, camera, resize_ctx=ctx)    # (V3:222: masks of another size are resized, on the GPU)
     M = stack.shape[0]
     sets = []
     if M == 0:
@@ -566,6 +589,37 @@ def filter_bboxes_in_camera_view(bboxes_3d, camera, verbose=True):
 # ---------------------------------------------------------------------------------------
 # exclusive labelling of Same_color.py:113-131 (first matching mask wins)
 # ---------------------------------------------------------------------------------------
+def _same_color_canvas(masks, camera):
+    """Same_color.py:124 indexes every mask AT ITS OWN SIZE -- ``y < mask.shape[0] and x < mask.shape[1] and mask[y, x] > 0.5``, no
+    resize -- so a mask that does not arrive at the camera's size counts in the pixels the two sizes share and nowhere else: the mask
+    cropped / zero-padded to [H, W].  Masks at camera size (and GPU tensors at camera size) pass through."""
+    H, W = camera.height, camera.width
+    if _is_device_tensor(masks):
+        import torch
+        if masks.ndim != 3:
+            raise ValueError("device masks must be [M,h,w]")
+        if tuple(masks.shape[1:]) == (H, W):
+            return _mask_stack(masks, camera)[0]
+        src = masks if masks.dtype in (torch.float32, torch.uint8) else masks.to(torch.float32)
+        canvas = torch.zeros((masks.shape[0], H, W), dtype=src.dtype, device=masks.device)
+        h, w = min(H, masks.shape[1]), min(W, masks.shape[2])
+        canvas[:, :h, :w] = src[:, :h, :w]
+        return canvas
+    planes = [np.asarray(mk) for mk in masks] if not isinstance(masks, np.ndarray) else list(masks)
+    if not planes:
+        return np.zeros((0, H, W), np.uint8)
+    if all(pl.shape == (H, W) for pl in planes):
+        return _mask_stack(np.stack(planes), camera)[0]
+    flt = any(pl.dtype.kind == "f" for pl in planes)
+    canvas = np.zeros((len(planes), H, W), np.float32 if flt else np.uint8)
+    for i, pl in enumerate(planes):                          # (the reference's list may hold masks of different sizes)
+        if pl.ndim != 2:
+            raise ValueError("masks must be a list of [h,w] arrays or an [M,h,w] array")
+        h, w = min(H, pl.shape[0]), min(W, pl.shape[1])
+        canvas[i, :h, :w] = pl[:h, :w]
+    return canvas
+
+
 def label_points_first_match(points, TrVeloToRect, camera, masks, mask_colors=None, depth_max=30.0, device=0):
     """Same_color.py's per-point double loop as one fused GPU pass.  Returns a dict:
     ``car_idx`` (indices into points of valid points that lie in some mask, ascending),
@@ -573,7 +627,7 @@ def label_points_first_match(points, TrVeloToRect, camera, masks, mask_colors=No
     (valid points in no mask), and ``colored_points`` / ``colored_colors`` / ``full_points`` as the
     reference accumulates them (colors = mask_colors[i] / 255.0 when mask_colors is given)."""
     p = _f32_points(points).reshape(-1, 4)
-    m = _mask_stack(masks, camera)
+    m = _same_color_canvas(masks, camera)
     if m.shape[0] > LPF_MAX_MASKS:
         raise ValueError("at most %d masks per frame" % LPF_MAX_MASKS)
     ctx = get_context(device)
@@ -637,20 +691,39 @@ def csv_rows(car_statistics, frame_number, timestamp=None):
              "timestamp": ts} for s in car_statistics]
 
 
+def _csv_cell(v):
+    """one value as pandas' to_csv writes it: bool -> True / False, integer -> digits, float -> shortest repr"""
+    if isinstance(v, (bool, np.bool_)):
+        return "True" if v else "False"
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        return repr(float(v))
+    return v
+
+
 def append_to_master_csv(car_statistics, frame_number, master_csv_path="results/master_car_statistics.csv", timestamp=None):
     if not car_statistics:
         return
-    import pandas as pd
+    import csv
     d = os.path.dirname(master_csv_path)
     if d:
         os.makedirs(d, exist_ok=True)
-    df = pd.DataFrame(csv_rows(car_statistics, frame_number, timestamp), columns=list(CSV_COLUMNS))
-    if os.path.exists(master_csv_path):
-        df.to_csv(master_csv_path, mode="a", header=False, index=False)
-        print(f"Appended {len(df)} rows to master CSV: {master_csv_path}")
-    else:
-        df.to_csv(master_csv_path, index=False)
+    # The bytes pandas' DataFrame(rows).to_csv(index=False) writes (cvs_erosion.py:257-265) -- integers as they are, floats by their
+    # shortest repr, booleans as True / False, minimal quoting, "\n" -- without building a DataFrame per frame: in a frame loop the
+    # DataFrame cost more than the frame's kernels (tests/test_pipeline_host.py compares the two writers byte for byte).
+    rows = csv_rows(car_statistics, frame_number, timestamp)
+    new_file = not os.path.exists(master_csv_path)
+    with open(master_csv_path, "a", newline="") as fh:
+        w = csv.writer(fh, lineterminator="\n")
+        if new_file:
+            w.writerow(CSV_COLUMNS)
+        for r in rows:
+            w.writerow([_csv_cell(r[c]) for c in CSV_COLUMNS])
+    if new_file:
         print(f"Created new master CSV: {master_csv_path}")
+    else:
+        print(f"Appended {len(rows)} rows to master CSV: {master_csv_path}")
 
 
 def analyze_master_csv(master_csv_path="results/master_car_statistics.csv"):
@@ -685,13 +758,83 @@ def default_colors(n):
     return [(int(i * 60) % 255, int(i * 120) % 255, int(i * 180) % 255) for i in range(n)]
 
 
+class FrameResult(dict):
+    """run_frames' dict of one frame.  The integers the kernels produced (valid_indices, count_mb, car_statistics, n_valid) are there
+    at once; the arrays of the reference's types that are GATHERS or CASTS of them -- ``points_valid`` (V3:592), ``car_point_sets``
+    (V3:228), ``u_valid`` / ``v_valid`` as int64 (V3:590-591), ``bg_assigned`` (V4:290-298) -- are made when they are first read (and
+    kept): a caller that writes the CSV never pays for 25 000-row fancy-index gathers it does not look at.  Every way of looking at a
+    dict sees the same keys and values as before."""
+    __slots__ = ("_lazy",)
+
+    def __init__(self, eager, lazy):
+        super().__init__(eager)
+        self._lazy = dict(lazy)                              # key -> zero-argument callable
+
+    def __missing__(self, key):
+        make = self._lazy.pop(key)                           # KeyError for a key that is neither
+        val = make()
+        self[key] = val
+        return val
+
+    def _all(self):
+        for k in list(self._lazy):
+            self[k]                                          # noqa: B018  (materialises)
+        return self
+
+    def get(self, key, default=None):
+        return self[key] if (key in self._lazy or dict.__contains__(self, key)) else default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def __iter__(self):
+        return dict.__iter__(self._all())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def keys(self):
+        return dict.keys(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def copy(self):
+        return dict(self._all())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._all(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self._all())
+
+
+class _DevicePoints:
+    """points[idx, :3] of a float32 [N,4] torch tensor on the GPU, as a NumPy array: the gather runs where the points are"""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, key):
+        idx, cols = key
+        import torch
+        i = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(self.t.device)
+        return self.t[i][:, cols].cpu().numpy()
+
+
 class FrameInputs:
     """What one frame hands to the hot path: velodyne points, detection masks and the
     visible boxes already in velodyne coordinates."""
 
     def __init__(self, frame, points, masks=None, bboxes_3d=None, colors=None, boxes_2d=None):
         self.frame = frame
-        self.points = points if isinstance(points, Scan) else _f32_points(points).reshape(-1, 4)
+        # (a Scan of the read-ahead reader or a float32 [N,4] torch tensor already on the GPU is taken as it is: no host copy)
+        self.points = points if (isinstance(points, Scan) or _is_device_tensor(points)) else _f32_points(points).reshape(-1, 4)
         self.masks = masks
         self.bboxes_3d = bboxes_3d if bboxes_3d is not None else []
         n = 0 if masks is None else len(masks)
@@ -711,9 +854,16 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     ctx = ctx or get_context(device)
     H, W = camera.height, camera.width
     ctx.set_camera(TrVeloToRect, camera.K, W, H, 0.0, float(depth_max))
-    # (masks of another size than the camera's: cv2.resize as V3:222, on the GPU -- not with the V3 erosion block, which erodes at the
-    #  masks' own size before the resize)
-    stacks = [_mask_stack(f.masks if f.masks is not None else [], camera, resize_ctx=None if (erode_iters or v3_pipeline) else ctx) for f in frames]
+    # (masks of another size than the camera's: cv2.resize as V3:222, on the GPU; with the V3 erosion block in force such masks are
+    #  eroded at their own size first, as V3:82-97 does before V3:222 -- and then so are the batch's other frames, by the same chain)
+    def _off_size(mk):
+        shp = tuple(getattr(mk, "shape", ())) if mk is not None else ()
+        return len(shp) == 3 and shp[0] > 0 and shp[1:] != (H, W)
+    chain_all = bool(erode_iters or v3_pipeline) and any(_off_size(f.masks) for f in frames)
+    stacks = [_mask_stack(f.masks if f.masks is not None else [], camera, resize_ctx=ctx, erode_iters=erode_iters, v3_pipeline=v3_pipeline,
+                          force_chain=chain_all)[0] for f in frames]
+    if chain_all:                                                        # the erosion has been done: the masks below are uint8 0 / 1 at camera size
+        erode_iters, v3_pipeline = 0, False
     M = max(s.shape[0] for s in stacks)
     if M > LPF_MAX_MASKS:
         # The reference loops over every mask (V3:220), with no bound; a launch labels a point with one bit per mask in a
@@ -750,18 +900,29 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
     out = []
     for f, r, s, pos in zip(frames, res, stacks, positions):
         m = s.shape[0]
+        # (the result arrays live in page-locked buffers the context reuses: what outlives this call is copied out of them here -- the
+        #  compact lists, a few hundred KB -- and the gathers / casts of the reference's types are made from those copies when read)
         vi = r["valid_idx"].copy()
-        host_pts = f.points.points if isinstance(f.points, Scan) else f.points     # Scan: pinned copy of the file
-        pts_valid = host_pts[vi, :3]
-        sets = [host_pts[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in r["inst_lists"][:m]]
+        uvv = np.stack([r["u_valid"], r["v_valid"]])                     # int32 [2, n_valid]
+        labv = r["label_valid"].copy()
+        lists = [l.copy() for l in r["inst_lists"][:m]]
+        is_scan = isinstance(f.points, Scan)
+        host_pts = f.points.points if is_scan else f.points              # Scan: pinned copy of the file
+        if _is_device_tensor(host_pts):                                  # points that live on the GPU: the gathers run there when asked for
+            host_pts = _DevicePoints(host_pts)
         stats = []
         if f.bboxes_3d and m:
             stats = stats_from_counts(r["inst_count"][:m], r["count_mb"][:m], f.colors, min_points, pos)
             for d in stats:
                 d.pop("_best_col"), d.pop("_best_count")
-        out.append(dict(frame=f.frame, valid_indices=vi, u_valid=r["u_valid"].astype(np.int64), v_valid=r["v_valid"].astype(np.int64),
-                        points_valid=pts_valid, car_point_sets=sets, bg_assigned=r["label_valid"] != 0,
-                        count_mb=r["count_mb"][:m].copy(), car_statistics=stats, n_valid=r["n_valid"]))
+        lazy = dict(u_valid=lambda uvv=uvv: uvv[0].astype(np.int64), v_valid=lambda uvv=uvv: uvv[1].astype(np.int64),
+                    points_valid=lambda p=host_pts, vi=vi: p[vi, :3],
+                    car_point_sets=lambda p=host_pts, ls=lists: [p[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in ls],
+                    bg_assigned=lambda labv=labv: labv != 0)
+        fr = FrameResult(dict(frame=f.frame, valid_indices=vi, count_mb=r["count_mb"][:m].copy(), car_statistics=stats, n_valid=r["n_valid"]), lazy)
+        if is_scan:
+            fr._all()                                        # (a Scan's pinned points are recycled when the reader moves on: gather now)
+        out.append(fr)
     return out
 
 

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblpf_oracle.so")
+_SO = os.environ.get("LPF_ORACLE_SO") or os.path.join(_HERE, "liblpf_oracle.so")      # (the sanitizer build: tests/test_host_sanitized.py)
 _lib = None
 
 _P = ctypes.c_void_p

@@ -133,3 +133,30 @@ def cv2_resize_linear_u8(src, W, H):
     S0, S1 = rows[sy], rows[sy1]                                             # [H, W]
     out = (((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2
     return out.astype(np.uint8)
+
+
+def cv2_erode_cross_u8(src, iterations=1):
+    """``cv2.erode(src_u8, cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (3, 3)), iterations=iterations)`` on 8-bit VALUES (V3:83-90),
+    restated: OpenCV's 3 x 3 ellipse is the cross [[0,1,0],[1,1,1],[0,1,0]]; erosion is the minimum over it; the default border value
+    of erode is +infinity, i.e. pixels outside the image do not take part.  THIRD-PARTY ALGORITHM, PINNED BY CONSTRUCTION ONLY (OpenCV
+    is not installed here; hand-made known answers in tests/test_oracle_masks.py)."""
+    a = np.ascontiguousarray(src, dtype=np.uint8)
+    for _ in range(int(iterations)):
+        p = np.pad(a, 1, constant_values=255)
+        a = np.minimum.reduce([p[1:-1, 1:-1], p[:-2, 1:-1], p[2:, 1:-1], p[1:-1, :-2], p[1:-1, 2:]])
+    return a
+
+
+def v3_masks_at_camera_size(masks, W, H, erosion_iterations=1):
+    """What V3 makes of detector masks [M,h,w] (float 0..1) that do NOT arrive at the camera's size, statement by statement:
+    ``(mask * 255).astype(np.uint8)`` -> ``cv2.erode(...)`` at the mask's own size -> ``.astype(np.float32) / 255.0`` (V3:82-97), then in
+    extract_car_points_by_mask ``cv2.resize(mask.astype(np.uint8), (W, H))`` and ``> 0.5`` (V3:222-225).  Returns uint8 [M,H,W], nonzero
+    = member."""
+    out = []
+    for m in np.asarray(masks):
+        u8 = (np.asarray(m, dtype=np.float32) * 255).astype(np.uint8)
+        er = cv2_erode_cross_u8(u8, erosion_iterations)
+        back = er.astype(np.float32) / 255.0
+        out.append((cv2_resize_linear_u8(back.astype(np.uint8), W, H) > 0.5).astype(np.uint8))
+    return np.stack(out) if out else np.zeros((0, H, W), np.uint8)
+

@@ -105,18 +105,20 @@ def test_rectangles_that_do_not_hold_show_what_is_skipped(mode, W, H):
 
 @pytest.mark.parametrize("mode", [False, "fused", "fused-pack"])
 @pytest.mark.parametrize("kind", ["u8", "f32"])
-@pytest.mark.parametrize("size", ["large", "small"])
+@pytest.mark.parametrize("size", ["large", "dense", "small"])
 def test_rectangles_that_do_not_hold_in_device_mode_launches_of_any_size(calib, mode, kind, size):
-    """Device-mode steps (the software-pipelined launches included): with the hint, tiles of ANY launch size read the lent masks inside
-    the rectangles only -- no pack rides, no label image is written.  Noise masks and rectangles that do not hold: every frame's
-    labels, lists and counts are those of the masks zeroed outside their rectangles.  uint8 masks and float masks (rule astype)."""
+    """Device-mode steps (the software-pipelined launches included): with the hint, the tiles of a launch of sparse frames of ANY size
+    ("large": 20 frames, 4 M points, the large geometry; "small") read the lent masks inside the rectangles only -- no pack rides, no
+    label image is written; dense frames ("dense": 900 k points on 530 k pixels) keep the pack, which honours the hint the same way.
+    Noise masks and rectangles that do not hold: every frame's labels, lists and counts are those of the masks zeroed outside their
+    rectangles, whichever form ran.  uint8 masks and float masks (rule astype)."""
     import torch
     from lidar_object_detection_amd import synthetic as S
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     _, T, K, W, H = S.default_calibration(calib)
     dev = torch.device("cuda", 0)
-    F, M = (5, 7) if size == "large" else (2, 7)
-    n = 900_000 if size == "large" else 60_000              # 4.5 M points: the large geometry (2048- / 1024-point tiles)
+    F, M = {"large": (20, 7), "dense": (5, 7), "small": (2, 7)}[size]
+    n = {"large": 200_000, "dense": 900_000, "small": 60_000}[size]     # large / dense: > 3.5 Mi points, the large geometry
     rng = np.random.default_rng(91 + F)
     scs = [S.scene(n + 977 * f, n_masks=M, n_boxes=6, seed=8400 + f, calib=calib) for f in range(F)]     # (frames that do not start on a multiple of 64)
     masks = (rng.random((F, M, H, W)) < 0.35).astype(np.uint8)
@@ -159,7 +161,7 @@ def test_rectangles_that_do_not_hold_in_device_mode_launches_of_any_size(calib, 
     for f, sc in enumerate(scs):
         ref = orc.run(sc["points"], T, K, W, H, 0.0, 40.0, label_img=orc.pack_masks(expect[f], 0, H, W), M=M, corners=sc["corners_velo"], want_float=False)
         a = int(off[f])
-        assert ref["inst_count"].sum() > 500 or f == 1
+        assert ref["inst_count"].sum() > 100 or f == 1
         assert np.array_equal(lab[a:a + sizes[f]], ref["label_bits"]), (mode, kind, f)
         assert np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"]), (mode, kind, f)
         assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"]), (mode, kind, f)

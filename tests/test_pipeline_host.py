@@ -242,3 +242,28 @@ def test_bench_usable_cpus_reads_cgroup_quota(tmp_path):
     assert bench.usable_cpus(str(tmp_path / "v1")) == min(aff, 2)
     (tmp_path / "none").mkdir()
     assert bench.usable_cpus(str(tmp_path / "none")) == aff
+
+
+def test_master_csv_bytes_equal_pandas(tmp_path):
+    """append_to_master_csv writes without a DataFrame per frame; the file must be, byte for byte, what the reference's
+    ``pd.DataFrame(rows).to_csv(path, index=False)`` / ``to_csv(path, mode='a', header=False, index=False)`` (cvs_erosion.py:257-265) writes."""
+    import pandas as pd
+    rng = np.random.default_rng(12)
+    ours, theirs = str(tmp_path / "a" / "m.csv"), str(tmp_path / "b.csv")
+    with contextlib.redirect_stdout(io.StringIO()):
+        for frame in (100, 250, 360, 1461):
+            stats = []
+            for car in range(int(rng.integers(1, 9))):
+                tot = int(rng.integers(1, 5000))
+                ins = int(rng.integers(0, tot + 1)) if rng.random() < 0.8 else 0
+                stats.append({"car_id": np.int64(car), "matched_bbox_id": int(rng.integers(0, 30)) if ins >= 10 else -1, "total_points": tot,
+                              "points_inside_bbox": np.int64(ins), "points_outside_bbox": tot - ins, "inside_percentage": ins / tot * 100,
+                              "outside_percentage": (tot - ins) / tot * 100, "color": (1, 2, 3)})
+            ts = "2025-06-14T10:%02d:00.123456" % (frame % 60) if frame != 360 else 'a "quoted", stamp'
+            pipeline.append_to_master_csv(stats, frame, ours, timestamp=ts)
+            df = pd.DataFrame(pipeline.csv_rows(stats, frame, ts), columns=list(pipeline.CSV_COLUMNS))
+            if os.path.exists(theirs):
+                df.to_csv(theirs, mode="a", header=False, index=False)
+            else:
+                df.to_csv(theirs, index=False)
+    assert open(ours, "rb").read() == open(theirs, "rb").read()

@@ -88,5 +88,91 @@ def test_masks_of_another_size_through_the_reference_shaped_calls(calib):
     assert len(sa) == 5 and sum(len(x) for x in sa) > 100
     for x, y in zip(sa, sb):
         assert np.array_equal(x, y)
-    with pytest.raises(NotImplementedError):                                              # the V3 erosion block erodes at the masks' own size first
-        pipeline.run_frames([pipeline.FrameInputs(1, sc["points"], small, boxes3d, pipeline.default_colors(5))], T, cam, 50.0, 10, True, erode_iters=1)
+
+
+def test_value_erosion_restatement_on_hand_made_planes():
+    """cv2.erode with the 3 x 3 ellipse (= cross) on 8-bit values: the minimum over the plus, the border left out (pinned by construction)"""
+    a = np.array([[9, 9, 9, 9], [9, 5, 9, 9], [9, 9, 9, 0]], np.uint8)
+    assert npp.cv2_erode_cross_u8(a, 1).tolist() == [[9, 5, 9, 9], [5, 5, 5, 0], [9, 5, 0, 0]]
+    assert npp.cv2_erode_cross_u8(a, 0).tolist() == a.tolist()
+    one = np.zeros((5, 5), np.uint8); one[1:4, 1:4] = 255
+    want = np.zeros((5, 5), np.uint8); want[2, 2] = 255
+    assert np.array_equal(npp.cv2_erode_cross_u8(one, 1), want) and not npp.cv2_erode_cross_u8(one, 2).any()
+    full = np.full((3, 4), 255, np.uint8)
+    assert np.array_equal(npp.cv2_erode_cross_u8(full, 3), full)            # the image border does not erode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("iters", [0, 1, 2, 3])
+def test_erosion_kernel_equals_the_restatement(calib, where, iters):
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext
+    _, T, K, W, H = S.default_calibration(calib)
+    rng = np.random.default_rng(40 + iters)
+    planes = np.stack([(rng.random((94, 353)) < 0.7).astype(np.uint8) * 255, rng.integers(0, 256, (94, 353)).astype(np.uint8), np.full((94, 353), 7, np.uint8)])
+    with LpfContext(0) as ctx:
+        ctx.set_camera(T, K, W, H, 0.0, 50.0)
+        out = ctx.erode_masks(planes, iters) if where == "host" else ctx.erode_masks(torch.from_numpy(planes).to(torch.device("cuda", 0)), iters).cpu().numpy()
+    for a, p in zip(out, planes):
+        assert np.array_equal(a, npp.cv2_erode_cross_u8(p, iters))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_v3_erosion_block_on_masks_of_another_size(calib, where):
+    """V3's own order for detector masks that do not arrive at camera size: (mask * 255).astype(uint8) -> cv2.erode at the MASK's size
+    -> / 255.0 (V3:82-97), then astype(uint8) + cv2.resize + > 0.5 in extract_car_points_by_mask (V3:222-225).  run_frames with
+    erode_iters=1, v3_pipeline=True on such masks == run_frames on the masks the restated chain produces (host and device masks; a batch
+    that mixes them with masks at camera size erodes those by the same chain)."""
+    import torch
+    from lidar_object_detection_amd import pipeline
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    cam = type("Cam", (), {"K": np.asarray(K), "width": W, "height": H})()
+    sc = S.scene(120_000, n_masks=5, n_boxes=12, seed=8300, calib=calib)
+    small = np.stack([m[::2, ::2] for m in sc["masks"]]).astype(np.float32)               # [5, H/2, W/2] float 0. / 1.
+    small[1] *= 0.999                                                                     # (mask * 255) -> 254: never 255 after the erosion's cast back
+    want_small = npp.v3_masks_at_camera_size(small, W, H, 1)
+    want_full = npp.v3_masks_at_camera_size(sc["masks"].astype(np.float32), W, H, 1)      # masks at camera size through the same statements
+    assert not want_small[1].any() and want_small[0].any() and (want_small[0] != npp.cv2_resize_linear_u8(small[0].astype(np.uint8), W, H)).any()
+    boxes3d = [{"corners_velo": c.tolist()} for c in sc["corners_velo"]]
+    to = (lambda a: torch.from_numpy(a).to(torch.device("cuda", 0))) if where == "device" else (lambda a: a)
+    items = [pipeline.FrameInputs(1, sc["points"], to(small), boxes3d, pipeline.default_colors(5))]
+    ref = [pipeline.FrameInputs(1, sc["points"], want_small, boxes3d, pipeline.default_colors(5))]
+    if where == "host":                                                                   # (a mixed batch: ragged device batches are refused elsewhere)
+        items.append(pipeline.FrameInputs(2, sc["points"], sc["masks"].astype(np.float32), boxes3d, pipeline.default_colors(5)))
+        ref.append(pipeline.FrameInputs(2, sc["points"], want_full, boxes3d, pipeline.default_colors(5)))
+    a = pipeline.run_frames(items, T, cam, 50.0, 10, True, erode_iters=1, v3_pipeline=True)
+    b = pipeline.run_frames(ref, T, cam, 50.0, 10, True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x["count_mb"], y["count_mb"]) and np.array_equal(x["bg_assigned"], y["bg_assigned"]) and sum(len(s_) for s_ in x["car_point_sets"]) > 100
+        for s1, s2 in zip(x["car_point_sets"], y["car_point_sets"]):
+            assert np.array_equal(s1, s2)
+
+
+@pytest.mark.gpu
+def test_same_color_indexes_a_mask_at_its_own_size(calib):
+    """Same_color.py:124: ``y < mask.shape[0] and x < mask.shape[1] and mask[y, x] > 0.5`` -- no resize; the first mask that matches
+    wins.  label_points_first_match with masks smaller / larger than the camera image == that loop, literally."""
+    from lidar_object_detection_amd import pipeline
+    from lidar_object_detection_amd import synthetic as S
+    _, T, K, W, H = S.default_calibration(calib)
+    cam = type("Cam", (), {"K": np.asarray(K), "width": W, "height": H})()
+    sc = S.scene(60_000, n_masks=3, n_boxes=2, seed=8301, calib=calib)
+    rng = np.random.default_rng(3)
+    masks = [(rng.random((200, 900)) < 0.3).astype(np.float32), (rng.random((500, 1500)) < 0.3).astype(np.float32), sc["masks"][2].astype(np.float32)]
+    got = pipeline.label_points_first_match(sc["points"], T, cam, masks, depth_max=30.0)
+    u, v, _, valid_indices = pipeline.project_points(sc["points"], T, cam, depth_max=30.0, want_depth=False)
+    car, first, bg = [], [], []
+    for idx in valid_indices:
+        x, y = u[idx], v[idx]
+        for i, mk in enumerate(masks):
+            if y < mk.shape[0] and x < mk.shape[1] and mk[y, x] > 0.5:
+                car.append(idx); first.append(i)
+                break
+        else:
+            bg.append(idx)
+    assert len(car) > 500 and len(set(first)) == 3
+    assert np.array_equal(got["car_idx"], car) and np.array_equal(got["car_mask"], first) and np.array_equal(got["background_idx"], bg)

@@ -32,8 +32,8 @@ o = dict(uv=torch.empty((F * n, 2), dtype=torch.int32, device=dev), label_bits=t
          valid_idx=torch.empty(F * n, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, n), dtype=torch.int64, device=dev),
          count_mb=torch.zeros(F * M * B, dtype=torch.int32, device=dev), summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
 torch.cuda.synchronize(dev)
-for mode in ("fused-pack", "fused", False):
-    for per_frame_boxes in (True, False):
+for mode, per_frame_boxes, one_call in [(m_, b_, False) for m_ in ("fused-pack", "fused", False) for b_ in (True, False)] + [("fused-pack", True, True), ("fused", True, True)]:
+    if True:
         with LpfContext(0) as ctx:
             ctx.set_pipelined(mode)
             ctx.set_camera(T, K, W, H, 0.0, 50.0)
@@ -41,6 +41,8 @@ for mode in ("fused-pack", "fused", False):
                 ctx.set_boxes_cam0_device(d_cam0, boff, Tcv, lend=True)
             fn = ctx.make_device_step(d_pts, off, masks_u8=d_masks, lend=True, boxes_cam0=d_cam0 if per_frame_boxes else None, box_off=boff,
                                       T_cam_to_velo=Tcv, inst_cap=n, **o)
+            if F == 1 and one_call:                         # lpf_run_frame: masks, boxes and the run in ONE C call
+                fn = ctx.make_frame_step(d_pts, masks_u8=d_masks[0], boxes_cam0=d_cam0 if per_frame_boxes else None, T_cam_to_velo=Tcv, inst_cap=n, **o)
             for _ in range(50):
                 fn()
             ctx.sync()
@@ -51,5 +53,6 @@ for mode in ("fused-pack", "fused", False):
             t1 = time.perf_counter()
             ctx.sync()
             t2 = time.perf_counter()
-            print("mode %-10s boxes %-9s F=%d: %.2f us per step, host calls %.2f us per step" % (
-                mode, "per step" if per_frame_boxes else "static", F, 1e6 * (t2 - t0) / reps, 1e6 * (t1 - t0) / reps), flush=True)
+            print("mode %-10s boxes %-9s F=%d%s: %.2f us per step, host calls %.2f us per step" % (
+                mode, "per step" if per_frame_boxes else "static", F, " ONE C call per frame (lpf_run_frame)" if (one_call and F == 1) else "",
+                1e6 * (t2 - t0) / reps, 1e6 * (t1 - t0) / reps), flush=True)
