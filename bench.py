@@ -49,7 +49,8 @@ ALGO_BYTES_PER_POINT = 28          # 16 B xyzI read + 8 B (u,v) write + 4 B labe
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-PMC_FILE = "r03_pmc_bench_f8x2M.json"
+PMC_FILE = (sorted(f for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")) if f.endswith("_pmc_bench_f8x2M.json")) or
+            ["r04_pmc_bench_f8x2M.json"])[-1]           # the newest round's committed counter pass
 
 
 def kernel_source_sha():
@@ -522,12 +523,39 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H, use_rects=True):
                     raise SystemExit("bench secondary configs[4]: GPU result differs from the CPU oracle")
         ctx.graph_destroy(gr)
         torch.set_num_threads(host_threads)
+        # the device side of such a frame alone: the same launch set -- box table set-up, mask pack + erosion, project+label, lists +
+        # box counts, summaries -- captured WITHOUT the copies (inputs resident in HBM), replayed back to back; and as plain launches
+        def device_work():
+            ctx.set_boxes_device(d_box, boff)
+            step()
+        device_work()
+        ctx.sync()
+        ctx.graph_begin()
+        device_work()
+        gd = ctx.graph_end()
+        for _ in range(20):
+            ctx.graph_launch(gd)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            ctx.graph_launch(gd)
+        ctx.sync()
+        dev_graph_us = 1e6 * (time.perf_counter() - t0) / 300
+        ctx.graph_destroy(gd)
+        t0 = time.perf_counter()
+        for _ in range(300):
+            device_work()
+        ctx.sync()
+        dev_plain_us = 1e6 * (time.perf_counter() - t0) / 300
         lat = 1e3 * np.array(lat[4:])
         out["configs4_stream_hipgraph_per_frame"] = {
             "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "p99_ms": float(np.percentile(lat, 99)),
             "max_ms": float(lat.max()), "frames_over_1ms": int((lat > 1.0).sum()),
             "frames": int(len(lat)), "paced_hz": 100, "points_per_frame": n, "masks_eroded_once": M, "boxes": B, "boxes_change_every_frame": True,
             "budget_ms_at_10Hz": 100.0,
+            "device_side_us_per_frame_graph_replay": dev_graph_us, "device_side_us_per_frame_plain_launches": dev_plain_us,
+            "device_side_note": "the frame's kernels alone, inputs resident in HBM, back to back: what is left of the p50 is PCIe -- 16 MB of points, "
+                                "4.2 MB of masks and the box corners in, counts and summary out -- and the host's wait",
             "includes": "H2D of points + masks + box corners (pinned), box table set-up, mask pack + erosion, project+label, lists + box counts, "
                         "finalize, D2H of counts + summary",
             "checked": "n_valid, inst_count, count_mb, best_box of the first 4 frames == CPU oracle"}

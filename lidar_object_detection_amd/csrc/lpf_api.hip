@@ -900,7 +900,7 @@ int lpf_sync(lpf_ctx *c)
 int lpf_set_geometry(lpf_ctx *c, int mode)
 {
     if (!c) return LPF_ERR_ARG;
-    if (mode < 0 || mode > 4) return fail(c, LPF_ERR_ARG, "lpf_set_geometry: mode=%d (0 by launch size, 1 small with the wide tail, 2 large, 3 large with scan-kernel prefixes, 4 small with the narrow tail)", mode);
+    if (mode < 0 || mode > 5) return fail(c, LPF_ERR_ARG, "lpf_set_geometry: mode=%d (0 by launch size, 1 small with the wide tail, 2 large, 3 large with scan-kernel prefixes, 4 small with the narrow tail, 5 small with 1024-point tiles)", mode);
     c->geometry = mode;
     ++c->generation;
     return LPF_OK;
@@ -1105,7 +1105,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 
     // ---- segmentation: segments of 4096 points (1024 for small launches), one list wave each; K1 tiles subdivide them;
     //      groups of 64 segments are the second level of the counters ------------------------------------------------
-    const bool small = c->geometry == 1 || c->geometry == 4 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
+    const bool small = c->geometry == 1 || c->geometry == 4 || c->geometry == 5 || (c->geometry == 0 && Ntot <= LPF_SMALL_LAUNCH);
     const int64_t seg_pts = small ? LPF_SEG_SMALL : LPF_SEG_QUANTUM;
     c->h_frames.resize(F);
     int nseg_total = 0, ngrp_total = 0, max_ngrp = 0;
@@ -1315,7 +1315,14 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     BX.last_ref = c->run_seq++;
 
     // small clouds: 512-point tiles (more, shorter blocks); large batches: 1024-point tiles
-    P.tile_pts = small ? 512 : 1024;
+    // Small geometry: 512-point tiles while they fit the chip's block slots in one round (256 CUs x 7 blocks: a real frame is 214
+    // tiles, a launch of a few frames a few hundred), one 1024-point tile per segment beyond -- a single mid-size cloud in 512-point
+    // tiles pays for a third, nearly empty round of blocks (one cloud per launch set, in order / pipelined, us: 1 M points 43.6 / 17.4
+    // -> 38.7 / 14.7, 2 M 39.2 / 21.4 -> 37.6 / 20.5, 3 M 63.9 / 28.4 -> 45.5 / 26.8).  Not for tiles that read M mask values per
+    // valid point (LpfDirect: 512-point form only; small sparse launches).  Lab geometry 5 forces the 1024-point form, 1 / 4 the other.
+    const bool plain_direct = (direct && !direct_rect) || (direct_fused && !direct_rect_fused);
+    const bool small_1024 = small && !plain_direct && (c->geometry == 5 || (c->geometry == 0 && Ntot > 1792ll * 512));
+    P.tile_pts = small ? (small_1024 ? 1024 : 512) : 1024;
     // the fused launch shares the chip with the previous run's tail blocks: 2048-point tiles keep twice the loads in flight
     // per wave, so the streaming work holds its bandwidth on fewer resident blocks (measured: 104.9 vs 108.8 us per step)
     if (fused && !small) P.tile_pts = direct_rect_fused ? LPF_RECT_FUSED_TILE : 2048;
@@ -1376,7 +1383,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
 #define LPF_K1_LAUNCH(R, LT) hipLaunchKernelGGL((lpf_k1_project_t<R, LPF_K1_FLAGS, LT>), g1, dim3(LPF_BLOCK), 0, c->stream, P)
         if (direct_rect) {
             typedef LpfDirectRect<uint8_t, 0> R0; typedef LpfDirectRect<float, 1> R1;
-            if (small) { if (!c->lazy.f32) LPF_K1_LAUNCH(2, R0); else LPF_K1_LAUNCH(2, R1); }
+            if (P.tile_pts == 512) { if (!c->lazy.f32) LPF_K1_LAUNCH(2, R0); else LPF_K1_LAUNCH(2, R1); }
             else       { if (!c->lazy.f32) LPF_K1_LAUNCH(4, R0); else LPF_K1_LAUNCH(4, R1); }
         } else if (direct) {
             typedef LpfDirect<uint8_t, 0> D0; typedef LpfDirect<float, 1> D1; typedef LpfDirect<float, 2> D2; typedef LpfDirect<float, 3> D3;
@@ -1384,7 +1391,7 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
             else if (c->lazy.mode == 1) LPF_K1_LAUNCH(2, D1);
             else if (c->lazy.mode == 2) LPF_K1_LAUNCH(2, D2);
             else LPF_K1_LAUNCH(2, D3);
-        } else if (small) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
+        } else if (P.tile_pts == 512) { if (lb == 1) LPF_K1_LAUNCH(2, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(2, uint16_t); else LPF_K1_LAUNCH(2, uint32_t); }
         else       { if (lb == 1) LPF_K1_LAUNCH(4, uint8_t); else if (lb == 2) LPF_K1_LAUNCH(4, uint16_t); else LPF_K1_LAUNCH(4, uint32_t); }
 #undef LPF_K1_LAUNCH
         LPF_HIP(c, hipGetLastError());

@@ -789,6 +789,7 @@ __device__ __forceinline__ void lpf_lists_wave(const LpfParams &P, const LpfFram
         if (nv > (unsigned)LPF_LIST_CAP || nv > 6u * (unsigned)nrows) {
             for (int r = 0; r < nrows; ++r) {
                 const unsigned long long rv = lpf_rl64(vb, r);                      // wave-uniform
+                if (rv == 0ull) continue;                   // (a real scan: rows are full or empty -- half of them hold no valid point)
                 const long long pos = lpf_rl(vbase, r) + __popcll(rv & lt);
                 if (((rv >> lane) & 1ull) && pos < room) {
                     dst[pos] = (long long)(seg_start + r * 64 + lane - sh);
@@ -1034,21 +1035,45 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
     const int rows_per_wave = P.tile_pts >> 8;
     const int rpw_shift = (rows_per_wave == 8) ? 3 : (rows_per_wave == 4) ? 2 : (rows_per_wave == 2) ? 1 : 0;
     auto exact = [&](int count) {
+        bool in = false;
+        int j = 0;
+        unsigned lb = 0u;
         if (lane < count) {
             const unsigned ent = qq[lane];
-            const int e = (int)(ent & 63u), j = (int)(ent >> 6);                    // point of the chunk, box of the word
+            const int e = (int)(ent & 63u);                                         // point of the chunk,
+            j = (int)(ent >> 6);                                                    // box of the word
             const float4 x = s_pt[e];
             const double px = (double)x.x, py = (double)x.y, pz = (double)x.z;
             const double *bp = s_bp + j * 16;
-            const bool in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
-            if (in) {
-                unsigned l = __float_as_uint(x.w);
+            in = P.oriented ? lpf_oriented_inside(px, py, pz, bp) : lpf_aabb_inside(px, py, pz, bp);
+            lb = __float_as_uint(x.w);
+        }
+        // Counting.  The pairs of a round are mostly ONE box and ONE mask -- the k-th candidate of 64 neighbouring points on the same
+        // car -- so 64 lanes adding 1 to the same LDS word is the common case and the slow one (a same-address atomic per lane, one
+        // after the other: a parked car annotated 17 times cost a chunk 17 such rounds, ~4 us).  Such a round adds its popcount once.
+        const unsigned long long inb = __ballot(in);
+        if (inb == 0ull) return;
+        const int src = __ffsll((long long)inb) - 1;
+        const int j0 = __builtin_amdgcn_readlane(j, src);
+        const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)lb, src);
+        if (__all(!in || (j == j0 && lb == l0))) {
+            if (lane == src) {
+                const unsigned n = (unsigned)__popcll(inb);
+                unsigned l = l0;
                 while (l) {
                     const int m = __ffs(l) - 1;
                     l &= l - 1;
-                    const int ci = m * LPF_BC_WORD + j;
-                    atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                    const int ci = m * LPF_BC_WORD + j0;
+                    atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? (n << 16) : n);
                 }
+            }
+        } else if (in) {
+            unsigned l = lb;
+            while (l) {
+                const int m = __ffs(l) - 1;
+                l &= l - 1;
+                const int ci = m * LPF_BC_WORD + j;
+                atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
             }
         }
     };
@@ -1072,17 +1097,10 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
     int qn = 0;                                             // wave-uniform queue length
     const int cell = lpf_ground_cell(p.y, s_dom[1], s_dom[3]) * LPF_GRID + lpf_ground_cell(p.x, s_dom[0], s_dom[2]);
     unsigned long long mset = act ? P.cand[fr.cand_off + (size_t)wd * LPF_GRID_WORDS + cell] : 0ull;
-    while (__any(mset != 0ull)) {
-        const bool has = mset != 0ull;
-        const int j = has ? __ffsll((long long)mset) - 1 : 0;
-        mset &= mset - 1ull;
-        bool near = false;
-        if (has) {
-            const float *sq = s_bq + 6 * j;
-            near = p.x >= sq[0] && p.x <= sq[3] && p.y >= sq[1] && p.y <= sq[4] && p.z >= sq[2] && p.z <= sq[5];
-        }
+    // pairs that pass the float bounds are queued; a full queue takes the exact test a whole wave at a time
+    auto enqueue = [&](const bool near, const int j) {
         const unsigned long long bal = __ballot(near);
-        if (!bal) continue;
+        if (!bal) return;
         if (near) qq[qn + __popcll(bal & lt)] = (unsigned)lane | ((unsigned)j << 6);
         qn += __popcll(bal);
         if (qn >= 64) {
@@ -1094,6 +1112,24 @@ __device__ __forceinline__ void lpf_count_chunk(const LpfParams &P, const LpfFra
             qn -= 64;
             __builtin_amdgcn_wave_barrier();
         }
+    };
+    // TWO candidates of every lane per round, their bounds read together: the loop is a chain of LDS round trips (bounds -> compare
+    // -> ballot -> queue), and a cell in a street of parked cars holds dozens of candidates (KITTI-360 annotates a car once per
+    // timestamp: 17 boxes on one parked car)
+    while (__any(mset != 0ull)) {
+        const bool has1 = mset != 0ull;
+        const int j1 = has1 ? __ffsll((long long)mset) - 1 : 0;
+        mset &= mset - 1ull;
+        const bool has2 = mset != 0ull;
+        const int j2 = has2 ? __ffsll((long long)mset) - 1 : 0;
+        mset &= mset - 1ull;
+        const float *s1 = s_bq + 6 * j1, *s2 = s_bq + 6 * j2;
+        const float a0 = s1[0], a1 = s1[1], a2 = s1[2], a3 = s1[3], a4 = s1[4], a5 = s1[5];
+        const float b0 = s2[0], b1 = s2[1], b2 = s2[2], b3 = s2[3], b4 = s2[4], b5 = s2[5];
+        const bool near1 = has1 && p.x >= a0 && p.x <= a3 && p.y >= a1 && p.y <= a4 && p.z >= a2 && p.z <= a5;
+        const bool near2 = has2 && p.x >= b0 && p.x <= b3 && p.y >= b1 && p.y <= b4 && p.z >= b2 && p.z <= b5;
+        enqueue(near1, j1);
+        enqueue(near2, j2);
     }
     __builtin_amdgcn_wave_barrier();
     exact(qn);

@@ -51,7 +51,7 @@ def lab_library():
     return _build.LAB_LIB if os.path.exists(_build.LAB_LIB) else None
 
 
-FORMS = ["auto", "small", "small-narrow", "large", "large-scan"]
+FORMS = ["auto", "small", "small-narrow", "small-1024", "large", "large-scan"]
 
 
 def context_for_form(form, device=0):

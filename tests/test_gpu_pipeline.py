@@ -444,6 +444,51 @@ def test_integration_md_device_mode_snippet_runs(calib):
     ns["lib"].lpf_destroy(ns["ctx"])
 
 
+def test_integration_md_frame_job_snippet_runs(calib):
+    """The one-call-per-frame snippet of INTEGRATION.md section C (lpf_frame_job / lpf_run_frame), executed as written after the stub:
+    frame 100's scan, its masks with their rectangles, its annotated boxes as cam-0 corners; results against the golden vectors."""
+    import ctypes
+    import re
+    import types
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## C. Raw ctypes stub"):]
+    blocks = re.findall(r"```python\n(.*?)```", sec, re.S)
+    stub, job_snip = blocks[0], [b for b in blocks if "lpf_run_frame" in b][0]
+    stub = stub.replace('ctypes.CDLL("lidar_object_detection_amd/liblpf.so")',
+                        'ctypes.CDLL(%r)' % os.path.join(root, "lidar_object_detection_amd", "liblpf.so"))
+    g = load_golden(100)
+    cam = _camera(calib)
+    masks = unpack_masks(g, "rect5", cam.height, cam.width)
+    ns = {"TrVeloToRect": calib["TrVeloToRect"], "camera": cam, "points": np.ascontiguousarray(g["points"]), "masks": masks, "m_": 2,
+          "bboxes_3d": [{"corners_velo": c.tolist()} for c in g["corners_velo"]]}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    from lidar_object_detection_amd._native import LpfContext
+    dev = torch.device("cuda", 0)
+    n, M, B = len(g["points"]), 5, len(g["corners_cam0_raw"])
+    d = dict(uv=torch.empty((n, 2), dtype=torch.int32, device=dev), lab=torch.empty(n, dtype=torch.int32, device=dev),
+             vidx=torch.empty(n, dtype=torch.int64, device=dev), iidx=torch.empty(n, dtype=torch.int64, device=dev),
+             cnt=torch.zeros(M * B, dtype=torch.int32, device=dev), summ=torch.zeros(928, dtype=torch.uint8, device=dev))
+    out = ns["Outputs"](uv=d["uv"].data_ptr(), label_bits=d["lab"].data_ptr(), valid_idx=d["vidx"].data_ptr(), inst_idx=d["iidx"].data_ptr(),
+                        inst_cap=n, count_mb=d["cnt"].data_ptr(), summary=d["summ"].data_ptr(), on_device=1)
+    m8 = masks.astype(np.uint8)
+    frame = types.SimpleNamespace(pts=torch.from_numpy(ns["points"]).to(dev), n=n, masks_u8=torch.from_numpy(m8).to(dev), M=M,
+                                  rects_i32=torch.from_numpy(LpfContext.mask_rects(m8)).to(dev),
+                                  corners_cam0=torch.from_numpy(np.ascontiguousarray(g["corners_cam0_raw"], dtype=np.float64)).to(dev), B=B, out=out)
+    torch.cuda.synchronize(dev)
+    ns.update(frame=frame, T_cam_to_velo=np.ascontiguousarray(np.linalg.inv(calib["TrVeloToCam"])))
+    ns["lib"].lpf_run_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    exec(compile(job_snip, "INTEGRATION.md", "exec"), ns)
+    ns["lib"].lpf_sync.argtypes = [ctypes.c_void_p]
+    assert ns["lib"].lpf_sync(ns["ctx"]) == 0
+    nv = len(g["valid_idx_d50"])
+    assert np.array_equal(d["vidx"].cpu().numpy()[:nv], g["valid_idx_d50"])
+    got = d["cnt"].cpu().numpy().reshape(M, B)
+    assert np.array_equal(got[:, g["visible_pos"]], g["count_mb_rect5_d50"])
+    ns["lib"].lpf_destroy(ns["ctx"])
+
+
 def test_integration_md_python_snippets_run(calib, tmp_path, monkeypatch):
     """Sections A and B of INTEGRATION.md executed as written on frame 100."""
     import re

@@ -18,6 +18,7 @@ from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE  # noqa
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 use_rects = len(sys.argv) > 2 and sys.argv[2] == "rects"
 which = sys.argv[3] if len(sys.argv) > 3 else "both"
+geometry = sys.argv[4] if len(sys.argv) > 4 else ""          # lab build: forced launch geometry (LpfContext.set_geometry)
 M, B = 8, 32
 dev = torch.device("cuda", 0)
 TrVeloToCam, T, K, W, H = S.default_calibration()
@@ -35,7 +36,10 @@ torch.cuda.synchronize(dev)
 res = []
 modes = {"both": (False, "fused-pack"), "serial": (False,), "fused": ("fused",), "fused-pack": ("fused-pack",)}[which]
 for mode in modes:
-    with LpfContext(0) as ctx:
+    from lidar_object_detection_amd import _build
+    with LpfContext(0, library=_build.LAB_LIB if geometry else None) as ctx:
+        if geometry:
+            ctx.set_geometry(geometry)
         ctx.set_pipelined(mode)
         ctx.set_camera(T, K, W, H, 0.0, 30.0)
         fns = [ctx.make_device_step(p_, np.array([0, n], np.int64), masks_u8=m_, lend=True, boxes_cam0=c_, box_off=np.array([0, B], np.int32),
@@ -51,4 +55,4 @@ for mode in modes:
         ctx.sync()
         res.append(1e6 * (time.perf_counter() - t0) / 600)
 print("one %d-point cloud per launch set (8 masks, 32 boxes, own masks and boxes every step%s): %s" % (
-    n, ", mask rectangles given" if use_rects else "", ", ".join("%s %.1f us per step" % (m or "in order", r) for m, r in zip(modes, res))), flush=True)
+    n, (", mask rectangles given" if use_rects else "") + (", geometry " + geometry if geometry else ""), ", ".join("%s %.1f us per step" % (m or "in order", r) for m, r in zip(modes, res))), flush=True)

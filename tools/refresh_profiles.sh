@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the measured artifacts under profiles/ on the GPU box (run through gpurun; outputs land in
 # gpurun_out/refresh/, copy them into profiles/ afterwards).  Counter passes are separate runs with
-# --kernel-trace only, as the pool requires.   usage: tools/refresh_profiles.sh [round tag, default r03] [pmc|quick]
+# --kernel-trace only, as the pool requires.   usage: tools/refresh_profiles.sh [round tag, default r04] [pmc|quick]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 WHAT=${2:-all}           # "pmc": only the counter passes and the bench lines that quote them; "quick": no probes
 O=$R/gpurun_out/refresh
 rm -rf "$O"; mkdir -p "$O"
@@ -42,21 +42,28 @@ done
 echo "[2b] kernel trace at the driver's arguments (fill and drain of the pipeline)"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktrace_driver" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-secondary --no-events > /dev/null 2> "$O/ktrace_driver.err"
 python3 "$R/tools/trace_list.py" "$(ls -t "$O"/ktrace_driver/*/*kernel_trace.csv | head -1)" 26 > "$O/${TAG}_timeline_driver_args.txt"; tail -6 "$O/${TAG}_timeline_driver_args.txt"
-echo "[2c] real scans at the headline's size (146 frames per step): kernels in order, and the fused step"
+echo "[2c] real scans at the headline's size (146 frames per step) with the masks' rectangles: kernels in order, and the fused step; then without them"
 for M in serial fused-pack; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_$M" -- python3 "$R/tools/real_probe.py" $M > "$O/real_$M.txt" 2> /dev/null
-  cp "$(ls -t "$O"/ktrace_real_$M/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_$M.csv"; cat "$O/real_$M.txt"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_$M" -- python3 "$R/tools/real_probe.py" $M rects > "$O/real_$M.txt" 2> /dev/null
+  cp "$(ls -t "$O"/ktrace_real_$M/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_${M}_mask_rects.csv"; cat "$O/real_$M.txt"
 done
-echo "[2d] the same with the masks' 2D rectangles (lpf_set_mask_rects), in order"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_rects" -- python3 "$R/tools/real_probe.py" serial rects > "$O/real_rects.txt" 2> /dev/null
-cp "$(ls -t "$O"/ktrace_real_rects/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_serial_mask_rects.csv"; cat "$O/real_rects.txt"
-timeout -k 10 200 python3 "$R/tools/real_probe.py" fused-pack rects 2> /dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ktrace_real_norects" -- python3 "$R/tools/real_probe.py" fused-pack > "$O/real_norects.txt" 2> /dev/null
+cp "$(ls -t "$O"/ktrace_real_norects/*/*kernel_stats.csv | head -1)" "$O/${TAG}_real146_kernel_stats_fused-pack_no_rects.csv"; cat "$O/real_norects.txt"
+echo "[2d] BASELINE configs[2] literally (one 2 M-point cloud per launch set): timelines in order and pipelined"
+for M in serial fused-pack; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$O/ktrace_cloud_$M" -- python3 "$R/tools/cloud_probe.py" 2000000 - $M > "$O/cloud_$M.txt" 2> /dev/null
+  { cat "$O/cloud_$M.txt"; python3 "$R/tools/trace_list.py" "$(ls -t "$O"/ktrace_cloud_$M/*/*kernel_trace.csv | head -1)" 12; } > "$O/${TAG}_timeline_configs2_one_cloud_$M.txt"; cat "$O/${TAG}_timeline_configs2_one_cloud_$M.txt"
+done
+echo "[2e] counter passes on the real-scan step and the synthetic step in order"
+( cd "$R" && PMC_SYNTH=1 bash tools/pmc_real.sh $TAG rects > "$O/pmc_real.log" 2>&1; tail -14 "$O/pmc_real.log"; cp gpurun_out/pmc_real/${TAG}_pmc_real146.json "$O/" )
+cd /tmp
 pmc
 lines
 [ "$WHAT" = quick ] && exit 0
 echo "[3] probes"
 timeout -k 10 200 python3 "$R/tools/frame100_bench.py" > "$O/${TAG}_frame100_configs01.json" 2> /dev/null; cut -c1-400 "$O/${TAG}_frame100_configs01.json"
 timeout -k 10 200 python3 "$R/tools/stream_latency.py" --frames 600 > "$O/${TAG}_stream_latency_configs4.json" 2> /dev/null; cut -c1-300 "$O/${TAG}_stream_latency_configs4.json"
-{ timeout -k 10 200 python3 "$R/tools/boxjob_probe.py"; timeout -k 10 200 python3 "$R/tools/stream_probe.py" 1; timeout -k 10 200 python3 "$R/tools/stream_probe.py" 20; timeout -k 10 200 python3 "$R/tools/frames_probe.py"; } 2> /dev/null | tee "$O/${TAG}_probes.txt"
+{ timeout -k 10 200 python3 "$R/tools/boxjob_probe.py"; timeout -k 10 200 python3 "$R/tools/stream_probe.py" 1; timeout -k 10 200 python3 "$R/tools/stream_probe.py" 20; timeout -k 10 200 python3 "$R/tools/frames_probe.py"; timeout -k 10 200 python3 "$R/tools/cloud_probe.py" 2000000; } 2> /dev/null | tee "$O/${TAG}_probes.txt"
+timeout -k 10 300 python3 "$R/tools/process_frames_bench.py" > "$O/${TAG}_process_frames.json" 2> /dev/null; cut -c1-400 "$O/${TAG}_process_frames.json"
 cut -d, -f1-4 "$O/${TAG}_bench_kernel_stats_fused-pack.csv" | grep lpf_ | cut -c1-110
 cut -d, -f1-4 "$O/${TAG}_bench_kernel_stats_serial.csv" | grep lpf_ | cut -c1-110
