@@ -1224,13 +1224,16 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     // pack, no label image (146 real frames per step: 176 -> 134 us).  Dense frames keep the pack: with 2 M points on 530 k pixels and
     // rectangles that cover a good part of the image every row meets a rectangle, and the exact test of such a row is a dependent round
     // trip (one 2 M-point cloud with 8 disk masks, tiles 18.5 -> 21 us, pipelined stream 21.4 -> 25.4 us per cloud).
-    const bool direct_rect_fused = c->ride.valid && fused && M > 0 && sparse_frames && c->ride.rects &&
+    // Small launches stay with the tiles that read all M mask bytes of a valid point (LpfDirect) and gate them by the rectangles: the
+    // candidate grid would be one more kernel in front of a launch that is as long as its chain (a single real frame in order 18.8 vs
+    // 23.0 us; pipelined 11.1 vs 10.2, 4 frames 21.1 vs 21.4, 20 frames 35.0 vs 36.6).
+    const bool direct_rect_fused = c->ride.valid && fused && M > 0 && sparse_frames && !small && c->ride.rects &&
                                    ((!c->ride.f32 && c->ride.mode == 0) || (c->ride.f32 && c->ride.mode == 1));
     const bool direct_fused = direct_rect_fused || (c->ride.valid && fused && small && sparse_frames && M > 0);
     const bool ride_pack = c->ride.valid && fused && !direct_fused && c->ride.can_ride && M > 0;
     if (c->ride.valid && !direct_fused && !ride_pack && (rc = pack_ride_now(c))) return rc;
     // masks left unpacked: a small serial launch reads them directly, anything else packs them now (same stream, ahead of K1)
-    const bool direct_rect = M > 0 && c->lazy.valid && !fused && sparse_frames && c->lazy.rects &&
+    const bool direct_rect = M > 0 && c->lazy.valid && !fused && sparse_frames && !small && c->lazy.rects &&
                              ((!c->lazy.f32 && c->lazy.mode == 0) || (c->lazy.f32 && c->lazy.mode == 1));
     const bool direct = direct_rect || (M > 0 && c->lazy.valid && small && sparse_frames && !fused);
     if (M > 0 && c->lazy.valid && !direct && (rc = ensure_packed(c))) return rc;
@@ -1240,12 +1243,13 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
     if (M > 0 && fused && !direct && c->mask_set != c->parity)
         return fail(c, LPF_ERR_STATE, "the masks were set for another scratch set: in the pipelined modes the label images rotate with the scratch sets -- call lpf_set_masks_* before every lpf_run* (and after switching modes)");
     P.label_img = (M > 0) ? (direct ? c->lazy.p : direct_fused ? c->ride.masks : SM.label_cur) : nullptr;
-    P.rects = direct_rect ? c->lazy.rects : direct_rect_fused ? c->ride.rects : nullptr;
+    // (the rectangles also gate the tiles that read all M mask bytes: small sparse launches)
+    P.rects = (direct && c->lazy.valid) ? c->lazy.rects : (direct_fused && c->ride.valid) ? c->ride.rects : nullptr;
     // ... whose tiles look a point's candidates up in a coarse grid of the rectangles (a few KB per frame), built once per run: by
     // blocks of this run's own launch where the tiles come a launch later (mode 4), else by a small kernel ahead of the tiles
     LpfRectJob RG;
     memset(&RG, 0, sizeof RG);
-    const bool rect_tiles = P.rects != nullptr;
+    const bool rect_tiles = direct_rect || direct_rect_fused;
     if (rect_tiles) {
         RG.rects = P.rects; RG.F = F; RG.M = M;
         RG.cw = (c->W + LPF_RG_CELL - 1) / LPF_RG_CELL; RG.ch = (c->H + LPF_RG_CELL - 1) / LPF_RG_CELL;

@@ -255,13 +255,17 @@ template <typename T, int MODE> struct LpfIsDirect<LpfDirectRect<T, MODE> > { st
 template <typename LT>
 struct LpfLabelSrc {                                         // packed label image [F][H][W] of LT
     typedef LT elem;
-    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ img, const LpfParams &, const int pix) { return (uint32_t)img[pix]; }
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ img, const LpfParams &, const int pix, const int4 *, int, int) { return (uint32_t)img[pix]; }
     static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.W * (size_t)P.H; }
 };
 template <typename T, int MODE>
 struct LpfLabelSrc<LpfDirect<T, MODE> > {                    // masks [F][M][H][W] of T
     typedef T elem;
-    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ msk, const LpfParams &P, const int pix)
+    // rc: the frame's rectangles (lpf_set_mask_rects) or null -- a mask counts inside its rectangle only, pixel for pixel, as in every
+    // other form that takes the hint (here all M bytes are read anyway: a small launch has no candidate grid, which would be one more
+    // kernel in front of the tiles -- in order 18.8 vs 23.0 us for a single real frame)
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__ msk, const LpfParams &P, const int pix, const int4 *__restrict__ rc,
+                                                   const int ui, const int vi)
     {
         const size_t hw = (size_t)P.W * (size_t)P.H;
         uint32_t l = 0;
@@ -273,6 +277,15 @@ struct LpfLabelSrc<LpfDirect<T, MODE> > {                    // masks [F][M][H][
             for (int j = 0; j < 8; ++j)
                 if (m0 + j < P.M && lpf_member<T, MODE>(v[j])) l |= 1u << (m0 + j);
         }
+        if (rc && l) {                                      // (divergent: only lanes that lie in some mask look at its rectangle)
+            uint32_t rest = l;
+            while (rest) {
+                const int m = __ffs(rest) - 1;
+                rest &= rest - 1u;
+                const int4 q = rc[m];
+                if (!(ui >= q.x && ui < q.z && vi >= q.y && vi < q.w)) l &= ~(1u << m);
+            }
+        }
         return l;
     }
     static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.M * (size_t)P.W * (size_t)P.H; }
@@ -282,7 +295,7 @@ template <typename T, int MODE>
 struct LpfLabelSrc<LpfDirectRect<T, MODE> > {                // masks [F][M][H][W] of T, read inside their rectangles only (lpf_k1_tile)
     typedef T elem;
     static constexpr int mode = MODE;
-    static __device__ __forceinline__ uint32_t get(const elem *__restrict__, const LpfParams &, const int) { return 0u; }      // (not used)
+    static __device__ __forceinline__ uint32_t get(const elem *__restrict__, const LpfParams &, const int, const int4 *, int, int) { return 0u; }      // (not used)
     static __device__ __forceinline__ size_t frame_stride(const LpfParams &P) { return (size_t)P.M * (size_t)P.W * (size_t)P.H; }
 };
 
@@ -356,7 +369,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
         uint32_t lab[ROWS];
         bool valid[ROWS];
         constexpr bool RECT = LpfIsDirectRect<LT>::value;
-        const int4 *__restrict__ rc_f = RECT ? P.rects + (size_t)f * P.M : nullptr;
+        const int4 *__restrict__ rc_f = ((RECT || LpfIsDirect<LT>::value) && P.rects) ? P.rects + (size_t)f * P.M : nullptr;
         const uint32_t *__restrict__ rgrid = (RECT && limg && P.rect_grid) ? P.rect_grid + (size_t)f * P.rg_cells : nullptr;
         const size_t mhw = (size_t)P.W * (size_t)P.H;
         unsigned long long myv = 0, mym = 0;                // lane r keeps the ballots of row r
@@ -413,7 +426,7 @@ __device__ __forceinline__ void lpf_k1_tile(const LpfParams &P, const int blk, u
                 if (ok && rgrid) lab[r] = rgrid[(vi >> LPF_RG_SHIFT) * P.rg_cw + (ui >> LPF_RG_SHIFT)];
             } else
             if (!(FL & LPF_F_LAB_NOGATHER)) {
-                if (ok && limg) lab[r] = Src::get(limg, P, vi * P.W + ui);
+                if (ok && limg) lab[r] = Src::get(limg, P, vi * P.W + ui, rc_f, ui, vi);
             }
             if (live && !(FL & LPF_F_LAB_NOSTORE)) {
                 const long long g = pbase + idx;
