@@ -56,7 +56,7 @@ def _case(seed, calib):
     return T, K, W, H, dmax, oriented, M, frames, masks, boxes
 
 
-@pytest.mark.parametrize("form", ["auto", "small-narrow", "large", "large-scan"])
+@pytest.mark.parametrize("form", ["auto", "small-narrow", "small-1024", "large", "large-scan"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24"))))
 def test_fuzz_against_oracle(seed, form, calib):
     from conftest import context_for_form
@@ -80,20 +80,23 @@ def test_fuzz_against_oracle(seed, form, calib):
             assert np.array_equal(r[k], o[k], equal_nan=True), (seed, form, f, k)
 
 
-@pytest.mark.parametrize("mode", ["fused", "fused+lent", "fused-pack+lent"])
+@pytest.mark.parametrize("mode", ["fused", "fused+lent", "fused-pack+lent", "fused+lent+rects", "fused-pack+lent+rects", "fused-pack+lent+rects+large", "off+lent+rects+large"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LPF_FUZZ_CASES", "24")) // 2))
 def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
-    """The same random cases through device mode under lpf_set_pipelined(2), three consecutive cases per context with nothing
+    """The same random cases through device mode under lpf_set_pipelined(2 / 4), three consecutive cases per context with nothing
     synchronised in between: the tail of case k rides in the launch of case k+1 (another shape, other masks and boxes), its
-    summaries in the launch of case k+2."""
+    summaries in the launch of case k+2.  "+rects": the masks' tight rectangles are given (lpf_set_mask_rects) -- results must not
+    change; "+large" forces the large launch geometry (lab build), under which the tiles read the lent masks inside the rectangles
+    through the candidate grid (LpfDirectRect; the grid rides in mode 4, goes ahead as a kernel in order)."""
     import torch
+    from conftest import context_for_form
     from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
     dev = torch.device("cuda", 0)
     base = int(os.environ.get("LPF_FUZZ_SEED_BASE", "1000"))
     cases = [_case(base + 3 * seed + j, calib) for j in range(3)]
     held = []
-    with LpfContext(0) as ctx:
-        ctx.set_pipelined(mode.split("+")[0])
+    with context_for_form("large" if "+large" in mode else "auto") as ctx:
+        ctx.set_pipelined(False if mode.startswith("off") else mode.split("+")[0])
         for T, K, W, H, dmax, oriented, M, frames, masks, boxes in cases:
             F = len(frames)
             sizes = [len(p) for p in frames]
@@ -112,6 +115,8 @@ def test_fuzz_software_pipelined_device_mode(seed, mode, calib):
             torch.cuda.synchronize(dev)
             ctx.set_camera(T, K, W, H, 0.0, dmax)
             if M:
+                if "+rects" in mode:
+                    ctx.set_mask_rects(LpfContext.mask_rects(np.stack(masks)))
                 ctx.set_masks(mt, lend="+lent" in mode)
             else:
                 ctx.clear_masks()
