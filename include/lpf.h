@@ -189,11 +189,16 @@ int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode
 /* Optional hint for the NEXT lpf_set_masks_* call with the same F and M: rects[F][M][4] = {x0, y0, x1, y1} (int32, pixels, half
  * open) -- the caller's word that mask m of frame f is zero outside its rectangle.  A detector hands out every mask with its 2D box
  * and crops the mask to it (the reference's segmenter returns them side by side, cvs_erosion.py:86-87, 110: `boxes`, `masks`); a real
- * frame's masks are a few per cent non-zero.  Where uint8 masks are packed as they are (no erosion; every mode) the pack then reads
- * only the 16-pixel groups that meet a mask's rectangle: the same results as without the hint as long as the caller's word holds;
- * every other form (float masks, erosion, small launches whose tiles read the masks themselves) ignores it.  on_device: 0 = host
- * memory, copied now without a wait; otherwise device memory (16-byte aligned) that is read when the masks are packed -- it must stay
- * unchanged until then, like lent masks.  rects = NULL clears a pending hint.  The hint is consumed by the next lpf_set_masks_*. */
+ * frame's masks are a few per cent non-zero.  With the hint a mask is READ AS ZERO OUTSIDE ITS RECTANGLE, pixel for pixel, by every
+ * form that takes it -- uint8 masks and float masks under binarize = 0, without erosion, image at least 16 pixels wide:
+ *   - launches of sparse frames (fewer points per frame than half the image has pixels) read the lent / staged masks THEMSELVES:
+ *     large launches through a per-frame candidate grid of the rectangles (16 x 16-pixel cells) and an exact test for the rows that
+ *     have a candidate -- no pack, no label image, whatever the launch size; small launches (a frame or a few) read a valid point's M
+ *     mask bytes and gate them by the rectangles;
+ *   - dense frames' masks are packed, and the pack reads a 16-pixel group of mask m only where it meets m's rectangle.
+ * The same results as without the hint as long as the caller's word holds; erosion and the other float rules ignore it.  on_device:
+ * 0 = host memory, copied now without a wait; otherwise device memory (16-byte aligned) that stays unchanged until the runs that use
+ * these masks have completed, like lent masks.  rects = NULL clears a pending hint.  The hint is consumed by the next lpf_set_masks_*. */
 int lpf_set_mask_rects(lpf_ctx *ctx, const int32_t *rects, int on_device, int F, int M);
 int lpf_set_masks_f32(lpf_ctx *ctx, const float *masks, int F, int M, int binarize,
                       int erode_iters, int on_device);
@@ -280,8 +285,9 @@ int lpf_depth_image(lpf_ctx *ctx, const float *pts, int64_t N, int on_device, do
 /* cv2.resize(mask.astype(np.uint8), (camera.width, camera.height)) (V3:222; INTER_LINEAR, the default) for masks that do not arrive at
  * the camera's size (the reference's scripts all pass retina_masks=True, so theirs do): n planes [h][w] of uint8 -> n planes [H][W]
  * (the size of lpf_set_camera), which then go to lpf_set_masks_u8 (nonzero = member = the reference's `> 0.5`).  Restated from
- * OpenCV 4.x resize.cpp (HResizeLinear / VResizeLinear, 11-bit weights) and pinned by construction only -- OpenCV is not part of this
- * image and the reference holds no resized fixture (oracle/numpy_path.py: cv2_resize_linear_u8 states the formula).  An exact 2 x 2
+ * OpenCV 4.x resize.cpp (HResizeLinear / VResizeLinear, 11-bit weights; the x axis clamps index and fraction at the ends, the y axis
+ * keeps the fraction and clips the two row indices) and pinned by construction only -- OpenCV is not part of this image and the
+ * reference holds no resized fixture (oracle/numpy_path.py: cv2_resize_linear_u8 states the formula).  An exact 2 x 2
  * decimation, which OpenCV hands to INTER_AREA, is refused.  on_device: both pointers in host (0) or device (1) memory; device
  * callers: in stream order.  Not capturable. */
 int lpf_resize_masks_u8(lpf_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst, int on_device);

@@ -89,7 +89,11 @@ def load(path=None):
     if lab is not None and _build.needs_build(path):
         have = _build.library_id(path)
         try:
-            _build.build(lab=lab)
+            import fcntl
+            with open(path + ".lock", "w") as lk:           # (the ranks of a multi-process run must not rebuild the file under each other)
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if _build.needs_build(path):
+                    _build.build(lab=lab)
         except Exception as e:
             raise LpfError(-2, "%s is %s and cannot be rebuilt here (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU path" % (

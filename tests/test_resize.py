@@ -176,3 +176,37 @@ def test_same_color_indexes_a_mask_at_its_own_size(calib):
             bg.append(idx)
     assert len(car) > 500 and len(set(first)) == 3
     assert np.array_equal(got["car_idx"], car) and np.array_equal(got["car_mask"], first) and np.array_equal(got["background_idx"], bg)
+
+
+@pytest.mark.gpu
+def test_masks_produced_on_a_side_stream_just_before_the_call(calib):
+    """Ordering (include/lpf.h, "Ordering contract"): masks that a long chain of kernels on ANOTHER torch stream is still
+    producing when resize_masks / erode_masks are called, results read back on that stream with no host-side wait in between: the
+    context draws an edge in from torch's current stream and an edge out to it."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext
+    _, T, K, W, H = S.default_calibration(calib)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    planes = (rng.random((4, 188, 704)) < 0.4).astype(np.uint8)
+    base = torch.from_numpy(planes).to(dev)
+    big = torch.rand((2048, 2048), device=dev)
+    torch.cuda.synchronize(dev)
+    side = torch.cuda.Stream(dev)
+    with LpfContext(0) as ctx:
+        ctx.set_camera(T, K, W, H, 0.0, 50.0)
+        ctx.resize_masks(base); ctx.erode_masks(base, 1)       # (allocations, outside the ordered region)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(side):
+            x = big
+            for _ in range(40):                             # a few milliseconds of work in front of the masks
+                x = (x @ big) * 1e-3
+            late = (base.to(torch.float32) + (x.sum() * 0.0)).to(torch.uint8)      # the masks: the last link of the chain
+            er = ctx.erode_masks(late.contiguous(), 1)
+            out = ctx.resize_masks(er)
+            got_er, got = er.cpu().numpy(), out.cpu().numpy()                       # (copies queued on the side stream)
+    for a, b, p in zip(got_er, got, planes):
+        want_er = npp.cv2_erode_cross_u8(p, 1)
+        assert np.array_equal(a, want_er)
+        assert np.array_equal(b, npp.cv2_resize_linear_u8(want_er, W, H))
