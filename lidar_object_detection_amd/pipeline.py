@@ -813,6 +813,9 @@ class FrameResult(dict):
     def __repr__(self):
         return dict.__repr__(self._all())
 
+    def __reduce__(self):                                    # pickles (and deep-copies) as the plain dict it stands for
+        return (dict, (dict(self._all()),))
+
 
 class _DevicePoints:
     """points[idx, :3] of a float32 [N,4] torch tensor on the GPU, as a NumPy array: the gather runs where the points are"""

@@ -267,3 +267,28 @@ def test_master_csv_bytes_equal_pandas(tmp_path):
             else:
                 df.to_csv(theirs, index=False)
     assert open(ours, "rb").read() == open(theirs, "rb").read()
+
+
+def test_frame_result_is_a_dict_whose_gathers_wait_until_read():
+    """run_frames' per-frame dict: the reference's gathered / cast arrays are made at first access and kept; every way of looking at
+    a dict sees all keys."""
+    import copy
+    import pickle
+    calls = []
+
+    def make():
+        calls.append(1)
+        return np.arange(4)
+    r = pipeline.FrameResult({"frame": 7, "n_valid": 4}, {"points_valid": make, "bg_assigned": lambda: np.ones(4, bool)})
+    assert r["frame"] == 7 and not calls
+    assert "points_valid" in r and len(r) == 4 and not calls
+    assert r.get("points_valid").sum() == 6 and r["points_valid"] is r["points_valid"] and len(calls) == 1
+    assert r.get("nothing", 3) == 3
+    with pytest.raises(KeyError):
+        r["nothing"]
+    assert sorted(r.keys()) == ["bg_assigned", "frame", "n_valid", "points_valid"] and sorted(k for k in r) == sorted(r.keys())
+    assert dict(r.items())["bg_assigned"].all() and len(list(r.values())) == 4 and len(calls) == 1
+    r["car_point_sets"] = [1]
+    r["car_point_sets"] += [2]
+    assert r["car_point_sets"] == [1, 2]
+    assert type(pickle.loads(pickle.dumps(r))) is dict and sorted(copy.deepcopy(r)) == sorted(r.keys()) and type(r.copy()) is dict
