@@ -56,3 +56,46 @@ for mode in modes:
         res.append(1e6 * (time.perf_counter() - t0) / 600)
 print("one %d-point cloud per launch set (8 masks, 32 boxes, own masks and boxes every step%s): %s" % (
     n, (", mask rectangles given" if use_rects else "") + (", geometry " + geometry if geometry else ""), ", ".join("%s %.1f us per step" % (m or "in order", r) for m, r in zip(modes, res))), flush=True)
+
+# ---- the verdict's experiment, emulated with what exists: ONE cloud cut into k sub-ranges that are queued as k consecutive runs of a
+#      software-pipelined context and drained at the end of the cloud (lpf_sync) -- the lists / box counts of range j ride among the
+#      tiles of range j + 1, the last range's tail and the summaries come in the drain's launches.  Each range gets its own lists (a
+#      real implementation would have to concatenate the instance lists afterwards: list m starts behind ALL of list m - 1), so this
+#      is a lower bound of what sub-range pipelining inside one lpf_run could cost.
+if which == "both" and not geometry:
+    for k, pmode in ((2, "fused"), (4, "fused"), (2, "fused-pack")):
+        with LpfContext(0) as ctx:
+            ctx.set_pipelined(pmode)
+            ctx.set_camera(T, K, W, H, 0.0, 30.0)
+            fns = []
+            for p_, m_, o, c_, r_ in bufs:
+                part = n // k
+                views = {kk: (v[:part] if v.shape[0] == n else v) for kk, v in o.items() if v is not None}      # (outputs of a range: the first part's buffers, reused)
+                fns.append([ctx.make_device_step(p_[j * part:(j + 1) * part], np.array([0, part], np.int64), masks_u8=m_, lend=True, boxes_cam0=c_,
+                                                 box_off=np.array([0, B], np.int32), T_cam_to_velo=Tcv, inst_cap=part,
+                                                 **{kk: (v if kk != "inst_idx" else v[:, :part]) for kk, v in views.items()}) for j in range(k)])
+            for _ in range(5):
+                for parts in fns:
+                    for f in parts:
+                        f()
+                    ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                for parts in fns:
+                    for f in parts:
+                        f()
+                    ctx.sync()                              # the cloud's results complete: an in-order run returns them at this point
+            print("the same cloud as %d sub-ranges, pipelined (%s) and drained per cloud: %.1f us per cloud (host sync included)" % (k, pmode, 1e6 * (time.perf_counter() - t0) / 300), flush=True)
+    with LpfContext(0) as ctx:                              # reference point with the same host-side sync: in order, one run per cloud
+        ctx.set_camera(T, K, W, H, 0.0, 30.0)
+        fns = [ctx.make_device_step(p_, np.array([0, n], np.int64), masks_u8=m_, lend=True, boxes_cam0=c_, box_off=np.array([0, B], np.int32),
+                                    T_cam_to_velo=Tcv, inst_cap=n, **o) for p_, m_, o, c_, r_ in bufs]
+        for _ in range(5):
+            for f in fns:
+                f(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            for f in fns:
+                f(); ctx.sync()
+        print("in order, one run per cloud, synchronised per cloud: %.1f us per cloud (host sync included)" % (1e6 * (time.perf_counter() - t0) / 300), flush=True)
+
