@@ -746,8 +746,25 @@ class LpfContext:
         off = np.zeros(F + 1, np.int64)
         off[1:] = np.cumsum([p.shape[0] for p in frames])
         n = int(off[-1])
-        pts = np.concatenate(frames, axis=0) if F > 1 else frames[0]
-        pts_ptr, pts_dev = (pts.ctypes.data if n else None), 0
+        batch_dev = None
+        if F > 1 and n and scan is None and dev_pts is None:
+            # several host frames: each goes to its place in ONE device tensor -- no concatenation of the batch on the host first
+            # (20 real frames are 37 MB: the copy cost as much as their kernels a hundred times over)
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    batch_dev = torch.empty((n, 4), dtype=torch.float32, device=torch.device("cuda", self.device))
+                    for f_, p_ in enumerate(frames):
+                        if p_.shape[0]:
+                            batch_dev[int(off[f_]):int(off[f_ + 1])].copy_(torch.from_numpy(p_))
+                    self.wait_for_stream(torch.cuda.current_stream(batch_dev.device).cuda_stream)
+            except ImportError:
+                batch_dev = None
+        if batch_dev is not None:
+            pts, pts_ptr, pts_dev = None, batch_dev.data_ptr(), 1
+        else:
+            pts = np.concatenate(frames, axis=0) if F > 1 else frames[0]
+            pts_ptr, pts_dev = (pts.ctypes.data if n else None), 0
         if scan is not None:
             scan._check_live()
             pts_ptr, pts_dev = (scan.dev_ptr if n else None), 1

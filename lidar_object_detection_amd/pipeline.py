@@ -845,6 +845,26 @@ class FrameInputs:
         self.boxes_2d = boxes_2d
 
 
+def _host_masks_to_device_batch(stacks, M, H, W, ctx):
+    """[F,M,H,W] torch tensor on the context's GPU holding the frames' host masks (float32 if any frame's are, else uint8; frames
+    with fewer detections padded with empty masks), or None when torch / its GPU support is not there."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+    except Exception:
+        return None
+    flt = any(s.dtype == np.float32 for s in stacks if s.shape[0])
+    dev = torch.device("cuda", ctx.device)
+    ragged = any(s.shape[0] != M for s in stacks)
+    t = (torch.zeros if ragged else torch.empty)((len(stacks), M, H, W), dtype=torch.float32 if flt else torch.uint8, device=dev)
+    for i, s in enumerate(stacks):
+        if s.shape[0]:
+            t[i, :s.shape[0]].copy_(torch.from_numpy(s if s.dtype == (np.float32 if flt else np.uint8) else s.astype(np.float32 if flt else np.uint8)))
+    ctx.wait_for_stream(torch.cuda.current_stream(dev).cuda_stream)    # the copies were queued on torch's stream
+    return t
+
+
 def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
                erode_iters=0, v3_pipeline=False, device=0, ctx=None):
     """Projection + clip + mask lookup + box counting + best-box scan for a list of
@@ -882,6 +902,10 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         batch = stacks[0][None] if len(stacks) == 1 else torch.stack(stacks)
         ctx.wait_for_stream(torch.cuda.current_stream(batch.device).cuda_stream)    # the masks were produced on torch's stream
         stacks = [np.empty((M, 0, 0), np.uint8)] * len(stacks)          # only their detection count is used below
+    elif len(stacks) > 1 and (batch := _host_masks_to_device_batch(stacks, M, H, W, ctx)) is not None:
+        # several frames of host masks: each frame's masks go to their place in ONE device tensor -- no np.stack of the batch on the
+        # host first (32 frames of five float masks are 340 MB: the copy cost more than everything else in the call)
+        stacks = [np.empty((s.shape[0], 0, 0), np.uint8) for s in stacks]
     elif all(s.shape[0] == M and s.dtype == (np.float32 if any(t.dtype == np.float32 for t in stacks if t.shape[0]) else np.uint8) for s in stacks):
         batch = stacks[0][None] if len(stacks) == 1 else np.stack(stacks)   # the usual case: no padding, no extra copy
     else:                                                               # ragged detection counts: pad with empty masks
