@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """A software-pipelined stream of single real frames (golden frame 100): microseconds per frame on the GPU and on the host (the
-time the calls themselves take: if it exceeds the GPU's, the stream is host-bound), with boxes per frame and with static boxes.
+time the calls themselves take in a loop of thousands -- which includes waiting for queue space once the host runs ahead of the GPU, so
+it approaches the GPU's figure from below when the stream is GPU-bound; tools/host_cost_probe.py times the calls' own CPU work), with boxes per
+frame and with static boxes.
 usage: python tools/stream_probe.py [frames-per-batch]"""
 import os
 import sys
