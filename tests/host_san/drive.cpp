@@ -21,7 +21,7 @@ static const char *ctx_err() { return lpf_last_error(g_ctx); }
 
 static const double T16[16] = {0, -1, 0, 0.1, 0, 0, -1, 0.2, 1, 0, 0, 0.3, 0, 0, 0, 1};
 static const double K9[9] = {552.5, 0, 682.0, 0, 552.5, 238.7, 0, 0, 1};
-static const int W = 128, H = 48;
+static const int W = 128, H = 48;                             // (a small image; pipelined_streams also runs a 1408 x 376 one)
 
 struct Dev {                      // "device" buffers: heap blocks, so that the sanitizer knows their bounds
     std::vector<void *> all;
@@ -141,8 +141,10 @@ static void host_memory_runs()
 }
 
 // the software-pipelined modes with everything new every run, long enough to lap the 8 MiB pinned ring several times
-static void pipelined_streams(int mode, int runs)
+static void pipelined_streams(int mode, int runs, const int W, const int H)
 {
+    // (W x H = 128 x 48: the frames are dense -- masks are packed, the pack rides in mode 4; 1408 x 376: sparse -- with rectangles the
+    //  tiles read the masks themselves, small launches gated, and large ones through the candidate grid, which rides in mode 4)
     lpf_ctx *c = nullptr;
     CHECK(lpf_create(&c, 0) == LPF_OK);
     g_ctx = c;
@@ -150,7 +152,7 @@ static void pipelined_streams(int mode, int runs)
     CHECK(lpf_set_pipelined(c, mode) == LPF_OK);
     Dev D;
     const int M = 4, FMAX = 6;
-    const int64_t NMAX = 40000;
+    const int64_t NMAX = (W > 1000) ? 6000000 : 40000;        // (the large image: now and then a launch beyond 3.5 Mi points, the large geometry)
     float *pts = D.get<float>(4 * NMAX);
     uint8_t *masks = D.get<uint8_t>((size_t)FMAX * M * W * H);
     double *dcorners = D.get<double>(24 * 64);
@@ -166,7 +168,8 @@ static void pipelined_streams(int mode, int runs)
         const int F = 1 + (int)rnd(FMAX);
         int64_t off[FMAX + 1];
         off[0] = 0;
-        for (int f = 0; f < F; ++f) off[f + 1] = off[f] + (int64_t)rnd((unsigned)(NMAX / FMAX));
+        const unsigned per_frame = (W > 1000 && it % 7 != 0) ? 200000u : (unsigned)(NMAX / FMAX);     // (mostly sparse frames on the large image)
+        for (int f = 0; f < F; ++f) off[f + 1] = off[f] + (int64_t)rnd(per_frame);
         // rectangles from host memory (F * M * 16 bytes <= 384: the 256-byte pieces that walked the ring's head to its end) or lent
         if (it % 3 != 2) CHECK(lpf_set_mask_rects(c, it % 3 ? hrects.data() : drects, it % 3 ? 0 : 1, F, M) == LPF_OK);
         CHECK(lpf_set_masks_u8(c, masks, F, M, 0, 2) == LPF_OK);
@@ -178,7 +181,15 @@ static void pipelined_streams(int mode, int runs)
         if (it % 5 == 0) CHECK(lpf_set_boxes_cam0(c, dcorners, 2, boff, F, Tcv, 1, 1, nullptr, nullptr, nullptr, nullptr) == (boff[F] <= 64 ? LPF_OK : LPF_OK));
         else CHECK(lpf_set_boxes_ex(c, hcorners.data(), 0, boff, F, it & 1) == LPF_OK);
         if (boff[F] > 64 && it % 5 == 0) CHECK(lpf_set_boxes_ex(c, hcorners.data(), 0, boff, F, 1) == LPF_OK);   // (the lent array holds 64 boxes)
-        CHECK(lpf_run_batch(c, pts, off, F, 1, &o) == LPF_OK);
+        if (F == 1 && it % 4 == 0) {                       // the one-call form: rectangles, lent masks, lent cam-0 corners, the run
+            lpf_frame_job j;
+            memset(&j, 0, sizeof j);
+            j.pts = pts; j.n_points = off[1]; j.masks = masks; j.mask_rects = drects; j.n_masks = M;
+            j.corners_cam0 = dcorners; j.n_boxes = 17; j.T_cam_to_velo = Tcv; j.filter_visible = 1; j.oriented = 1; j.out = o;
+            CHECK(lpf_run_frame(c, &j) == LPF_OK);
+        } else {
+            CHECK(lpf_run_batch(c, pts, off, F, 1, &o) == LPF_OK);
+        }
         if (it % 1000 == 999) CHECK(lpf_release_to_stream(c, nullptr) == LPF_OK);
     }
     int64_t st[8];
@@ -299,8 +310,11 @@ int main(int argc, char **argv)
     argument_errors();
     host_memory_runs();
     ring_of_small_uploads();
-    pipelined_streams(2, runs);
-    pipelined_streams(4, runs);
+    pipelined_streams(2, runs, W, H);
+    pipelined_streams(4, runs, W, H);
+    pipelined_streams(2, runs / 8, 1408, 376);
+    pipelined_streams(4, runs / 8, 1408, 376);
+    pipelined_streams(0, runs / 8, 1408, 376);               // in order: the candidate grid goes ahead of the tiles as a kernel
     graphs();
     reader(tmp);
     fprintf(stderr, "drive: %d failed checks, %lld fake launches\n", g_fail, fake_hip_launches());
