@@ -288,7 +288,7 @@ int lpf_depth_image(lpf_ctx *ctx, const float *pts, int64_t N, int on_device, do
  * OpenCV 4.x resize.cpp (HResizeLinear / VResizeLinear, 11-bit weights; the x axis clamps index and fraction at the ends, the y axis
  * keeps the fraction and clips the two row indices) and pinned by construction only -- OpenCV is not part of this image and the
  * reference holds no resized fixture (oracle/numpy_path.py: cv2_resize_linear_u8 states the formula).  An exact 2 x 2
- * decimation, which OpenCV hands to INTER_AREA, is refused.  on_device: both pointers in host (0) or device (1) memory; device
+ * decimation (h == 2 H and w == 2 W) is what OpenCV hands to INTER_AREA: the rounded mean (a + b + c + d + 2) >> 2.  on_device: both pointers in host (0) or device (1) memory; device
  * callers: in stream order.  Not capturable. */
 int lpf_resize_masks_u8(lpf_ctx *ctx, const uint8_t *src, int n, int h, int w, uint8_t *dst, int on_device);
 

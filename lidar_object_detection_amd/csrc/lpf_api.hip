@@ -1525,30 +1525,37 @@ int lpf_resize_masks_u8(lpf_ctx *c, const uint8_t *src, int n, int h, int w, uin
                                     "32-bit arithmetic -- and at most 2^36 pixels in all, in and out)", n, h, w, (const void *)src, (void *)dst);
     if (n == 0) return LPF_OK;
     const int W = c->W, H = c->H;
-    if (w == 2 * W && h == 2 * H)
-        return fail(c, LPF_ERR_ARG, "resize_masks: cv2.resize hands an exact 2 x 2 decimation to INTER_AREA, which is not restated here");
+    const bool area2 = w == 2 * W && h == 2 * H;              // cv2.resize hands this one to INTER_AREA: the rounded mean of 2 x 2 pixels
     const size_t in_bytes = (size_t)n * h * w, out_bytes = (size_t)n * H * W;
     int rc;
     if (c->capturing) return fail(c, LPF_ERR_STATE, "resize_masks inside a graph capture");
     if (anything_owed(c) && (rc = sync_all(c))) return rc;                // (the staging buffers below may be in use by owed runs)
     const uint8_t *dS = src;
     uint8_t *dD = dst;
+    const bool linear = !area2 && !(h == H && w == W);
     std::vector<int4> xt, yt;
-    resize_table(W, w, true, xt);
-    resize_table(H, h, false, yt);
     const size_t tab_bytes = ((size_t)W + (size_t)H) * sizeof(int4);
     if ((rc = reserve(c, c->resize_buf, tab_bytes + (on_device ? 0 : in_bytes + out_bytes)))) return rc;
-    // the tables are host vectors of this call: they travel through the pinned ring (copied now, queued in stream order), so a
-    // device-mode call returns without waiting for the GPU
-    if ((rc = upload(c, c->resize_buf.p, xt.data(), (size_t)W * sizeof(int4)))) return rc;
-    if ((rc = upload(c, (char *)c->resize_buf.p + (size_t)W * sizeof(int4), yt.data(), (size_t)H * sizeof(int4)))) return rc;
+    if (linear) {
+        resize_table(W, w, true, xt);
+        resize_table(H, h, false, yt);
+        // the tables are host vectors of this call: they travel through the pinned ring (copied now, queued in stream order), so a
+        // device-mode call returns without waiting for the GPU
+        if ((rc = upload(c, c->resize_buf.p, xt.data(), (size_t)W * sizeof(int4)))) return rc;
+        if ((rc = upload(c, (char *)c->resize_buf.p + (size_t)W * sizeof(int4), yt.data(), (size_t)H * sizeof(int4)))) return rc;
+    }
     if (!on_device) {
         dS = (const uint8_t *)c->resize_buf.p + tab_bytes;
         dD = (uint8_t *)c->resize_buf.p + tab_bytes + in_bytes;
         LPF_HIP(c, hipMemcpyAsync((void *)dS, src, in_bytes, hipMemcpyHostToDevice, c->stream));
     }
-    if ((h == H && w == W)) {
+    if (!linear && !area2) {
         LPF_HIP(c, hipMemcpyAsync(dD, dS, out_bytes, hipMemcpyDeviceToDevice, c->stream));       // cv2.resize to the same size copies
+    } else if (area2) {
+        const long long quads = (long long)n * H * ((W + 3) / 4);
+        hipLaunchKernelGGL(lpf_resize_area2_u8_kernel, dim3((unsigned)((quads + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,
+                           dS, dD, W, H, quads);
+        LPF_HIP(c, hipGetLastError());
     } else {
         const long long total = (long long)out_bytes;
         hipLaunchKernelGGL(lpf_resize_linear_u8_kernel, dim3((unsigned)((total + LPF_BLOCK - 1) / LPF_BLOCK)), dim3(LPF_BLOCK), 0, c->stream,

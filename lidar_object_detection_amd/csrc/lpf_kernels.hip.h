@@ -1672,6 +1672,26 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_resize_linear_u8_kernel(const u
     dst[i] = (uint8_t)((((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// The one case cv2.resize(..., INTER_LINEAR) does not compute linearly: a source of exactly twice the target in BOTH axes is handed to
+// INTER_AREA (resize(): `if (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation =
+// INTER_AREA`), whose 8-bit single-channel 2 x 2 path (ResizeAreaFastVec, scalar and SIMD alike) is the rounded mean of the four
+// source pixels: (a + b + c + d + 2) >> 2.  A thread produces four destination pixels of a row from two 8-byte runs (W % 4 tails
+// pixel by pixel).
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_resize_area2_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                                        const int W, const int H, const long long quads)
+{
+    const long long i = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x;
+    if (i >= quads) return;
+    const int qw = (W + 3) >> 2;                                  // quads per destination row
+    const long long row = i / qw;                                 // plane * H + y
+    const int x0 = (int)(i - row * qw) * 4, nx = min(4, W - x0);
+    const uint8_t *__restrict__ s0 = src + (size_t)row * 4 * W + 2 * x0;    // source row 2y of the same plane: (plane * 2H + 2y) * 2W
+    const uint8_t *__restrict__ s1 = s0 + 2 * W;
+    uint8_t *__restrict__ d = dst + (size_t)row * W + x0;
+    for (int k = 0; k < nx; ++k)
+        d[k] = (uint8_t)(((int)s0[2 * k] + (int)s0[2 * k + 1] + (int)s1[2 * k] + (int)s1[2 * k + 1] + 2) >> 2);
+}
+
 // cv2.erode(plane_u8, getStructuringElement(MORPH_ELLIPSE, (3, 3))) on 8-bit VALUES (V3:83-90 on masks that are not at camera size,
 // where the erosion comes before the resize, V3:222): the minimum over the plus-shaped neighbourhood, pixels outside the image left
 // out (OpenCV's erode border is +infinity).  One iteration, n planes [h][w]; a thread per pixel.

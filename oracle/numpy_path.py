@@ -101,14 +101,18 @@ def cv2_resize_linear_u8(src, W, H):
         under both weights: ``((b0 * t) >> 16) + ((b1 * t) >> 16)``, whose two truncations are not those of ``(2048 * t) >> 16``;
       * horizontal pass, 32-bit: ``S = src[sx] * a0 + src[min(sx + 1, w - 1)] * a1`` (beyond the last source column: src[sx] * 2048);
       * vertical pass: ``dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2``.
-    Not restated: the exact 2 x 2 decimation case, which OpenCV hands to INTER_AREA (raises NotImplementedError), and whatever a
-    SIMD / IPP build of OpenCV rounds differently.  Equal sizes return the input (cv2.resize copies)."""
+    The exact 2 x 2 decimation (h == 2 H and w == 2 W) is not linear in OpenCV: ``resize()`` switches it to INTER_AREA (``if
+    (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA``), whose 8-bit
+    one-channel 2 x 2 path (``ResizeAreaFastVec``: the scalar loop and the SIMD one compute the same) is
+    ``(S[2x] + S[2x+1] + nextS[2x] + nextS[2x+1] + 2) >> 2``.  Not restated: whatever a SIMD / IPP build of OpenCV rounds
+    differently in the linear case.  Equal sizes return the input (cv2.resize copies)."""
     src = np.ascontiguousarray(src, dtype=np.uint8)
     h, w = src.shape
     if (h, w) == (H, W):
         return src.copy()
-    if w == 2 * W and h == 2 * H:
-        raise NotImplementedError("cv2.resize hands an exact 2 x 2 decimation to INTER_AREA")
+    if w == 2 * W and h == 2 * H:                                         # INTER_AREA's 2 x 2 fast path
+        s = src.astype(np.int64)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
     def coeffs(n_dst, n_src, clamp):
         scale = 1.0 / (float(n_dst) / float(n_src))                       # double, as resize() computes it

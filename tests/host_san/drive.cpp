@@ -74,8 +74,12 @@ static void argument_errors()
     CHECK(lpf_run_frame(c, nullptr) == LPF_ERR_ARG);
     CHECK(lpf_allreduce_metrics(c, nullptr, 1, 0, nullptr) == LPF_ERR_ARG);
     CHECK(lpf_resize_masks_u8(c, nullptr, 1, 4, 4, nullptr, 0) == LPF_ERR_ARG);
-    uint8_t px[64] = {0}, out[W * H];
-    CHECK(lpf_resize_masks_u8(c, px, 1, 2 * H, 2 * W, out, 0) == LPF_ERR_ARG);   // the INTER_AREA case
+    uint8_t px[64] = {0};
+    {
+        std::vector<uint8_t> big((size_t)4 * W * H, 1), out((size_t)W * H);
+        CHECK(lpf_resize_masks_u8(c, big.data(), 1, 2 * H, 2 * W, out.data(), 0) == LPF_OK);   // the INTER_AREA case: no weight tables
+        CHECK(lpf_resize_masks_u8(c, big.data(), 1, 2 * H, W, out.data(), 0) == LPF_OK);       // twice in one axis: linear, with tables
+    }
     CHECK(lpf_erode_masks_u8(c, px, 1, 8, 8, 1, px, 0) == LPF_ERR_ARG);          // src == dst
     CHECK(strlen(lpf_build_id()) > 0 && lpf_abi_version() == LPF_ABI_VERSION);
     void *pin = lpf_host_alloc(1000);

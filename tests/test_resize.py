@@ -34,14 +34,32 @@ def test_restatement_on_hand_derived_values():
     got = npp.cv2_resize_linear_u8(edge, 6, 4)
     assert got[:, 3].tolist() == [0, 0, 0, 0]           # (rows 1, 2 blend the two equal source rows under 1536 / 512: the same sum; a fraction
                                                         #  clamped to 0 in rows 0 and 3 -- the x loop's rule -- would give [1, 0, 0, 1])
-    # equal sizes: a copy; an exact 2 x 2 decimation is OpenCV's INTER_AREA case: refused
+    # equal sizes: a copy
     assert np.array_equal(npp.cv2_resize_linear_u8(src, 4, 3), src)
-    with pytest.raises(NotImplementedError):
-        npp.cv2_resize_linear_u8(np.zeros((8, 8), np.uint8), 4, 4)
+    # an exact 2 x 2 decimation is the case OpenCV hands to INTER_AREA: the rounded mean of each 2 x 2 block, (sum + 2) >> 2 --
+    # by hand: [[1, 2], [3, 4]] -> (10 + 2) >> 2 = 3; [[0, 1], [0, 0]] -> 3 >> 2 = 0; [[1, 1], [0, 0]] -> 4 >> 2 = 1;
+    # [[255, 255], [255, 254]] -> 1021 >> 2 = 255
+    blk = np.array([[1, 2, 0, 1, 1, 1, 255, 255], [3, 4, 0, 0, 0, 0, 255, 254]], np.uint8)
+    assert npp.cv2_resize_linear_u8(blk, 4, 1).tolist() == [[3, 0, 1, 255]]
+    # a 0 / 1 mask halved: a block survives iff at least two of its four pixels are set
+    m = np.array([[1, 0, 1, 1, 0, 0], [0, 0, 0, 0, 0, 1], [1, 1, 1, 0, 1, 1], [1, 1, 0, 1, 1, 0]], np.uint8)
+    assert npp.cv2_resize_linear_u8(m, 3, 2).tolist() == [[0, 1, 0], [1, 1, 1]]
+    # twice in ONE axis only stays linear (is_area_fast also needs iscale_y == 2)
+    assert npp.cv2_resize_linear_u8(np.array([[0, 255, 255, 0]], np.uint8), 2, 1).tolist() == [[128, 128]]
+    # (the hand-over does not change a single byte: at an exact halving the linear path samples every block's centre with weights
+    #  1024 / 1024 in both axes, ((1024 * (((a + b) * 1024) >> 4)) >> 16) = a + b without loss, so it is (a + b + c + d + 2) >> 2 too --
+    #  checked here on random bytes by forcing the linear formula through a 2 x 2 tiling of the same image at one-axis halvings)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (12, 20)).astype(np.uint8)
+    s = img.astype(np.int64)
+    horiz = ((s[:, 0::2] + s[:, 1::2]) * 1024)                                       # the linear horizontal pass at fx = 0.5
+    lin = (((1024 * (horiz[0::2] >> 4)) >> 16) + ((1024 * (horiz[1::2] >> 4)) >> 16) + 2) >> 2
+    assert np.array_equal(npp.cv2_resize_linear_u8(img, 10, 6), lin.astype(np.uint8))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hw", [(188, 704), (104, 384), (160, 608), (376, 1408), (500, 1900), (1, 1), (3, 2000), (533, 17), (200, 1408)])
+@pytest.mark.parametrize("hw", [(188, 704), (104, 384), (160, 608), (376, 1408), (500, 1900), (1, 1), (3, 2000), (533, 17), (200, 1408),
+                                (752, 2816), (752, 1408), (376, 2816)])      # (twice the camera in both axes: INTER_AREA; in one axis: linear)
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_kernel_equals_the_restatement(calib, hw, where):
     import torch
