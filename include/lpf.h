@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LPF_MAX_MASKS 32          /* instances per frame: one bit each in label_bits */
-#define LPF_ABI_VERSION 7          /* 2: lpf_outputs gained uv_valid / label_valid
+#define LPF_ABI_VERSION 8          /* 2: lpf_outputs gained uv_valid / label_valid
                                       3: lpf_set_stream(ctx, NULL) is the null stream (was: an internal stream -> lpf_use_own_stream);
                                          lpf_set_pipelined modes; stale graphs are refused
                                       4: on_device = 2 (lent masks) in lpf_set_masks_*; lpf_set_pipelined(4)
@@ -43,7 +43,9 @@ extern "C" {
                                          lpf_set_pipelined modes 1 / 3 and lpf_set_cu_partition removed (measured slower, DESIGN.md
                                          section 8); lpf_set_geometry only in lab builds (-DLPF_LAB)
                                       6: lpf_set_mask_rects, lpf_resize_masks_u8 (added; nothing else changed)
-                                      7: lpf_build_id, lpf_host_alloc / lpf_host_free, lpf_run_frame, lpf_erode_masks_u8 (added; nothing else changed) */
+                                      7: lpf_build_id, lpf_host_alloc / lpf_host_free, lpf_run_frame, lpf_erode_masks_u8 (added; nothing else changed)
+                                      8: lpf_reader_submit_frame, lpf_reader_boxes, lpf_parse_boxes_json (added); lpf_resize_masks_u8 no longer
+                                         refuses an exact halving (it is cv2.resize's INTER_AREA case) */
 
 typedef enum lpf_status {
     LPF_OK = 0,
@@ -381,6 +383,29 @@ int  lpf_reader_submit(lpf_reader *rd, const char *path);
 int  lpf_reader_next(lpf_reader *rd, const float **d_pts, const float **h_pts, int64_t *n_points);
 int  lpf_reader_wait(lpf_reader *rd);
 void lpf_reader_destroy(lpf_reader *rd);
+
+/* A frame's second file: bboxes_3D_cam0/BBoxes_<frame>.json, which the reference reads with json.load (load_bounding_boxes,
+ * V3:31-38; cvs_erosion.py:333): a list of {"index": int, "corners_cam0": [[x, y, z] x 8]}.  Parsing 270 KB of 17-digit numbers
+ * (frame 2449, 314 boxes) costs a Python frame loop more than all of its GPU work, so the reader's worker can do it beside the scan:
+ *   lpf_reader_submit_frame  as lpf_reader_submit, plus the frame's box file (NULL: none).
+ *   lpf_reader_boxes         the box file of the scan handed out by the last lpf_reader_next: *state says what became of it
+ *                            (LPF_BOXES_*); when PARSED, *corners_cam0 = float64 [*nbox][8][3] -- what lpf_prepare_boxes /
+ *                            lpf_set_boxes_cam0 take -- and *index = int32 [*nbox], host memory of the reader, valid until the next
+ *                            lpf_reader_next.  A missing or unexpected box file never fails the scan.
+ *   lpf_parse_boxes_json     the same parser on its own (no context, no GPU): fills the caller's arrays of capacity cap boxes;
+ *                            *nbox = boxes in the file; more than cap: LPF_ERR_ARG with *nbox set (file size / 64 boxes always do).
+ * Numbers are converted with strtod in the C locale -- correctly rounded, as Python's float() is: the same doubles.  OTHER means the
+ * file is not that plain schema (other keys, a float index, NaN / Infinity, escapes in keys, malformed or trailing text) and has NOT
+ * been interpreted: hand it to a JSON library, whose result or error is then the reference's. */
+enum lpf_boxes_state {
+    LPF_BOXES_PARSED = 0,          /* corners and indices are there (possibly zero boxes: the reference skips such a frame) */
+    LPF_BOXES_ABSENT = 1,          /* no such file: the reference prints "No bounding boxes found" and skips the frame */
+    LPF_BOXES_OTHER = 2,           /* not the plain schema / unreadable: not interpreted */
+    LPF_BOXES_NONE = 3             /* no box file was submitted with that scan */
+};
+int  lpf_reader_submit_frame(lpf_reader *rd, const char *scan_path, const char *boxes_path);
+int  lpf_reader_boxes(lpf_reader *rd, const double **corners_cam0, const int32_t **index, int *nbox, int *state);
+int  lpf_parse_boxes_json(const char *path, double *corners_cam0, int32_t *index, int cap, int *nbox, int *state);
 
 #ifdef __cplusplus
 }

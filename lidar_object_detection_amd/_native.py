@@ -159,6 +159,9 @@ def load(path=None):
     lib.lpf_reader_create.argtypes = [_P, ctypes.POINTER(_P), ctypes.c_int, _I64]
     lib.lpf_reader_submit.argtypes = [_P, ctypes.c_char_p]
     lib.lpf_reader_next.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I64)]
+    lib.lpf_reader_submit_frame.argtypes = [_P, ctypes.c_char_p, ctypes.c_char_p]
+    lib.lpf_reader_boxes.argtypes = [_P, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.lpf_parse_boxes_json.argtypes = [ctypes.c_char_p, _P, _P, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.lpf_reader_wait.argtypes = [_P]
     lib.lpf_reader_destroy.argtypes = [_P]
     lib.lpf_reader_destroy.restype = None
@@ -173,7 +176,32 @@ EXPORTED = ("lpf_abi_version", "lpf_build_id", "lpf_host_alloc", "lpf_host_free"
             "lpf_get_label_image", "lpf_set_boxes", "lpf_set_boxes_ex", "lpf_set_boxes_cam0", "lpf_run", "lpf_run_batch", "lpf_run_frame",
             "lpf_points_in_boxes", "lpf_prepare_boxes", "lpf_depth_image", "lpf_resize_masks_u8", "lpf_erode_masks_u8", "lpf_get_stats", "lpf_profile_enable", "lpf_profile_read", "lpf_profile_overhead",
             "lpf_graph_begin", "lpf_graph_end", "lpf_graph_launch", "lpf_graph_destroy",
-            "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy")
+            "lpf_reader_create", "lpf_reader_submit", "lpf_reader_next", "lpf_reader_wait", "lpf_reader_destroy",
+            "lpf_reader_submit_frame", "lpf_reader_boxes", "lpf_parse_boxes_json")
+
+BOXES_PARSED, BOXES_ABSENT, BOXES_OTHER, BOXES_NONE = 0, 1, 2, 3          # enum lpf_boxes_state
+
+
+def parse_boxes_file(path):
+    """``(state, index int32[B], corners_cam0 f64[B,8,3])`` of a ``BBoxes_<frame>.json`` file, parsed by the library
+    (lpf_parse_boxes_json: no GPU involved; the doubles are json.load's).  state: BOXES_PARSED, BOXES_ABSENT (no such file) or
+    BOXES_OTHER -- the file is not the plain ``[{"index": int, "corners_cam0": 8 x 3 numbers}, ...]`` and was not interpreted (use
+    json.load)."""
+    lib = load()
+    path = os.fspath(path)
+    try:
+        cap = os.path.getsize(path) // 64 + 1          # (a box is at least 92 characters of text)
+    except OSError:
+        cap = 0
+    corners, index = np.empty((cap, 8, 3), np.float64), np.empty(cap, np.int32)
+    n, st = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib.lpf_parse_boxes_json(path.encode(), corners.ctypes.data if cap else None, index.ctypes.data if cap else None, cap,
+                                  ctypes.byref(n), ctypes.byref(st))
+    if rc != 0:
+        raise LpfError(rc, "lpf_parse_boxes_json(%s): %d boxes, room for %d" % (path, n.value, cap))
+    if st.value != BOXES_PARSED:
+        return st.value, np.empty(0, np.int32), np.empty((0, 8, 3), np.float64)
+    return BOXES_PARSED, index[:n.value], corners[:n.value]
 
 
 def _is_torch(x):
@@ -195,10 +223,13 @@ class Scan:
     """One velodyne scan handed out by ScanReader: ``points`` is a float32 [N,4] NumPy view of the
     pinned host copy (what loadVelodyneData returns, V3:24-28), ``dev_ptr`` its copy in HBM.  Both
     are only valid until the reader's next scan is fetched; copy ``points`` to keep it."""
-    __slots__ = ("path", "n", "points", "dev_ptr", "_reader", "_ticket")
+    __slots__ = ("path", "n", "points", "dev_ptr", "_reader", "_ticket", "boxes_state", "box_index", "boxes_cam0")
 
-    def __init__(self, path, n, points, dev_ptr, reader, ticket):
+    def __init__(self, path, n, points, dev_ptr, reader, ticket, boxes_state=BOXES_NONE, box_index=None, boxes_cam0=None):
         self.path, self.n, self.points, self.dev_ptr, self._reader, self._ticket = path, n, points, dev_ptr, reader, ticket
+        # the frame's box file when the reader was given one (ScanReader(box_paths=...)): BOXES_* and, when PARSED, COPIES of the
+        # reader's arrays: int32 [B], float64 [B,8,3]
+        self.boxes_state, self.box_index, self.boxes_cam0 = boxes_state, box_index, boxes_cam0
 
     def _check_live(self):
         if self._reader._ticket != self._ticket or self._reader._h is None:
@@ -210,11 +241,15 @@ class ScanReader:
     into pinned memory and copies them to HBM while the current scan is processed (lpf_reader_*).
     A missing file raises LpfError('<path> does not exist!') for that scan, like V3:26-27."""
 
-    def __init__(self, ctx, paths, n_buffers=3, max_points=1 << 21):
+    def __init__(self, ctx, paths, n_buffers=3, max_points=1 << 21, box_paths=None):
         self._ctx, self._lib = ctx, ctx._lib
         self._h = None
         self._ticket = 0
         self._paths = [os.fspath(p) for p in paths]
+        # box_paths[i]: the BBoxes_<frame>.json of scan i (or None) -- parsed by the reader's worker beside the scan
+        self._box_paths = None if box_paths is None else [None if b is None else os.fspath(b) for b in box_paths]
+        if self._box_paths is not None and len(self._box_paths) != len(self._paths):
+            raise ValueError("box_paths: one entry per scan")
         self._next_submit = 0
         self._delivered = 0
         self._depth = int(n_buffers)
@@ -226,7 +261,8 @@ class ScanReader:
 
     def _top_up(self):                         # keep n_buffers - 1 scans ahead of the consumer
         while self._next_submit < len(self._paths) and self._next_submit - self._delivered < self._depth:
-            self._ctx._check(self._lib.lpf_reader_submit(self._h, self._paths[self._next_submit].encode()))
+            bp = self._box_paths[self._next_submit] if self._box_paths is not None else None
+            self._ctx._check(self._lib.lpf_reader_submit_frame(self._h, self._paths[self._next_submit].encode(), bp.encode() if bp else None))
             self._next_submit += 1
 
     def __iter__(self):
@@ -251,7 +287,19 @@ class ScanReader:
             pts = np.frombuffer(buf, dtype=np.float32).reshape(cnt, 4)
         else:
             pts = np.zeros((0, 4), np.float32)
-        return Scan(path, cnt, pts, d.value, self, self._ticket)
+        state, bidx, bcam = BOXES_NONE, None, None
+        if self._box_paths is not None:
+            pc, pi, nb, st = _P(), _P(), ctypes.c_int(0), ctypes.c_int(BOXES_NONE)
+            self._ctx._check(self._lib.lpf_reader_boxes(self._h, ctypes.byref(pc), ctypes.byref(pi), ctypes.byref(nb), ctypes.byref(st)))
+            state = int(st.value)
+            if state == BOXES_PARSED:
+                b = int(nb.value)
+                if b:
+                    bcam = np.frombuffer((ctypes.c_double * (b * 24)).from_address(pc.value), dtype=np.float64).reshape(b, 8, 3).copy()
+                    bidx = np.frombuffer((ctypes.c_int32 * b).from_address(pi.value), dtype=np.int32).copy()
+                else:
+                    bcam, bidx = np.empty((0, 8, 3), np.float64), np.empty(0, np.int32)
+        return Scan(path, cnt, pts, d.value, self, self._ticket, state, bidx, bcam)
 
     def wait(self):
         self._ctx._check(self._lib.lpf_reader_wait(self._h))
@@ -446,6 +494,15 @@ class LpfContext:
                                              float(depth_min), float(depth_max)))
         self._camera = key
         self.W, self.H = int(width), int(height)
+
+    def ensure_intrinsics(self, K, width, height):
+        """The camera's K, width and height are in force -- all that lpf_prepare_boxes reads of the camera.  A frame loop that prepares
+        boxes and runs frames in turn keeps the run's camera (no lpf_set_camera per frame: that call rebuilds the box tables)."""
+        K3 = np.ascontiguousarray(np.asarray(K, dtype=np.float64)[:3, :3]).reshape(9)
+        cam = getattr(self, "_camera", None)
+        if cam is not None and cam[1] == K3.tobytes() and cam[2] == int(width) and cam[3] == int(height):
+            return
+        self.set_camera(np.eye(4), K3.reshape(3, 3), width, height, 0.0, 1.0)
 
     BINARIZE = {"astype": 0, "v3": 1, "gt0.5": 2}
 

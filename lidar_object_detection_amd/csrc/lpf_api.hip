@@ -156,6 +156,8 @@ struct lpf_ctx {
     // after an event recorded when it was left has completed (one event per 2 MB of uploads, not per upload).
     struct PinRing { char *base = nullptr; size_t cap = 0, head = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool rec[4] = {false, false, false, false}; } ring;
 
+    struct PinBack { char *p = nullptr; size_t cap = 0; } pin_back;   // page-locked landing area of small results (lpf_prepare_boxes)
+
     // host-io staging
     DevBuf pib_box, pib_pts, pib_out, boxprep, dimg, coll;
     DevBuf st_uvv, st_labv;
@@ -824,6 +826,7 @@ void lpf_destroy(lpf_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ring.ev) if (e) (void)hipEventDestroy(e);
     if (c->ring.base) (void)hipHostFree(c->ring.base);
+    if (c->pin_back.p) (void)hipHostFree(c->pin_back.p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1663,9 +1666,20 @@ int lpf_prepare_boxes(lpf_ctx *c, const double *corners_cam0, int nbox, const do
     const size_t nb = (size_t)nbox;
     const size_t o_in = 0, o_cv = o_in + nb * 192, o_bb = o_cv + nb * 192, o_fr = o_bb + nb * 32, o_vis = o_fr + nb * 4, total = o_vis + nb;
     int rc;
+    if (c->capturing) return fail(c, LPF_ERR_STATE, "prepare_boxes inside a graph capture");
     if ((rc = reserve(c, c->boxprep, total))) return rc;
     char *base = (char *)c->boxprep.p;
-    LPF_HIP(c, hipMemcpyAsync(base + o_in, corners_cam0, nb * 192, hipMemcpyHostToDevice, c->stream));
+    // in through the pinned ring, back through a page-locked landing area in ONE copy (the four results lie behind each other): a
+    // pageable pointer on either side makes every hipMemcpyAsync a blocking staged copy -- five of them were 0.9 ms per frame of
+    // process_frames, fifty times the kernel
+    if ((rc = upload(c, base + o_in, corners_cam0, nb * 192))) return rc;
+    const size_t back = total - o_cv;
+    if (c->pin_back.cap < back) {
+        if (c->pin_back.p) { LPF_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pin_back.p); c->pin_back.p = nullptr; c->pin_back.cap = 0; }
+        const size_t cap = back + back / 2 + 4096;
+        LPF_HIP(c, hipHostMalloc((void **)&c->pin_back.p, cap, hipHostMallocDefault));
+        c->pin_back.cap = cap;
+    }
     LpfBoxPrep A;
     memcpy(A.Tcv, Tcv, sizeof A.Tcv);
     memcpy(A.K, c->K, sizeof A.K);
@@ -1674,11 +1688,13 @@ int lpf_prepare_boxes(lpf_ctx *c, const double *corners_cam0, int nbox, const do
                        (const double *)(base + o_in), nbox, (uint8_t *)(base + o_vis), (double *)(base + o_cv), (double *)(base + o_bb),
                        (int *)(base + o_fr));
     LPF_HIP(c, hipGetLastError());
-    if (visible) LPF_HIP(c, hipMemcpyAsync(visible, base + o_vis, nb, hipMemcpyDeviceToHost, c->stream));
-    if (corners_velo) LPF_HIP(c, hipMemcpyAsync(corners_velo, base + o_cv, nb * 192, hipMemcpyDeviceToHost, c->stream));
-    if (bbox2d) LPF_HIP(c, hipMemcpyAsync(bbox2d, base + o_bb, nb * 32, hipMemcpyDeviceToHost, c->stream));
-    if (front) LPF_HIP(c, hipMemcpyAsync(front, base + o_fr, nb * 4, hipMemcpyDeviceToHost, c->stream));
+    LPF_HIP(c, hipMemcpyAsync(c->pin_back.p, base + o_cv, back, hipMemcpyDeviceToHost, c->stream));
     LPF_HIP(c, host_wait(c));
+    const char *h = c->pin_back.p - o_cv;                         // (the landing area starts at the corners)
+    if (visible) memcpy(visible, h + o_vis, nb);
+    if (corners_velo) memcpy(corners_velo, h + o_cv, nb * 192);
+    if (bbox2d) memcpy(bbox2d, h + o_bb, nb * 32);
+    if (front) memcpy(front, h + o_fr, nb * 4);
     return LPF_OK;
 }
 

@@ -16,7 +16,7 @@ from datetime import datetime
 
 import numpy as np
 
-from . import kitti360
+from . import _native, kitti360
 from ._native import LpfContext, LPF_MAX_MASKS, Scan, ScanReader
 
 _CONTEXTS = {}
@@ -127,21 +127,24 @@ def transform_bboxes_to_velodyne(bboxes_3d, TrVeloToCam):
     return bboxes_3d
 
 
-def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0, keep_all=False):
+def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0, keep_all=False, as_arrays=False):
     """filter_visible_bboxes + transform_bboxes_to_velodyne (+ V4's projected 2D box) in one GPU call
     (SURVEY 8f-1): returns the visible boxes, in order, each a copy of the input dict with
     'corners_velo' (list, as the reference stores it) and '_bbox2d' / '_front' for the IoU match.
     The camera of the context is set to (camera.K, width, height).  ``keep_all=True`` skips the
-    visibility filter (V5 transforms every box, V5:454-461)."""
+    visibility filter (V5 transforms every box, V5:454-461).  ``as_arrays=True`` (callers that keep the boxes to themselves, like
+    process_frames, whose only product is the CSV) stores 'corners_velo' as the f64 [8,3] array instead of the reference's
+    ``.tolist()`` of it -- the same values; 7 500 Python floats per frame of 314 boxes that nobody reads cost more than the frame's kernels."""
     have = [b for b in bboxes_3d_raw if "corners_cam0" in b]
     if not have:
         return []
     ctx = get_context(device)
-    ctx.set_camera(np.eye(4), camera.K, camera.width, camera.height, 0.0, 1.0)
+    ctx.ensure_intrinsics(camera.K, camera.width, camera.height)
     corners = np.array([b["corners_cam0"] for b in have], np.float64).reshape(-1, 8, 3)
     vis, cv, bb, fr = ctx.prepare_boxes(corners, np.linalg.inv(TrVeloToCam))
-    out = []
-    cv_l, bb_l, fr_l, vis_l = cv.tolist(), bb.tolist(), fr.tolist(), vis.tolist()      # (one conversion each: per box it cost more than the kernels)
+    out = _PreparedBoxes()
+    bb_l, fr_l, vis_l = bb.tolist(), fr.tolist(), vis.tolist()      # (one conversion each: per box it cost more than the kernels)
+    cv_l = cv if as_arrays else cv.tolist()
     for i, b in enumerate(have):
         if vis_l[i] or keep_all:
             d = dict(b)
@@ -150,11 +153,46 @@ def prepare_boxes(bboxes_3d_raw, camera, TrVeloToCam, device=0, keep_all=False):
             d["_bbox2d"] = bb_l[i] if fr_l[i] > 0 else None
             d["_front"] = fr_l[i]
             out.append(d)
+    out.cv = cv if keep_all else cv[vis]
+    return out
+
+
+class _PreparedBoxes(list):
+    """prepare_boxes' list of box dicts, with the corners of all of them as ONE float64 [B,8,3] array beside it (``cv``: what
+    run_frames hands to the GPU, without a walk over the dicts).  A list in every other respect; ``cv`` is dropped by anything that
+    makes a new list of it (slices, filters), and ``_corners_velo`` only trusts it while the lengths agree."""
+    __slots__ = ("cv",)
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.cv = None
+
+
+def prepare_boxes_from_arrays(index, corners_cam0, camera, TrVeloToCam, device=0, keep_all=False):
+    """prepare_boxes for a box file the library has parsed (lpf_parse_boxes_json / the read-ahead reader: ``index`` int32 [B],
+    ``corners_cam0`` float64 [B,8,3] -- the doubles json.load gives): the visible boxes, in order, as dicts with 'index',
+    'corners_velo' (the f64 [8,3] array, as prepare_boxes(as_arrays=True) stores it), '_bbox2d' / '_front'.  The cam-0 corners are
+    not copied into per-box lists: this is the form for callers that keep the boxes to themselves (process_frames)."""
+    corners = np.ascontiguousarray(corners_cam0, dtype=np.float64).reshape(-1, 8, 3)
+    out = _PreparedBoxes()
+    if not len(corners):
+        return out
+    ctx = get_context(device)
+    ctx.ensure_intrinsics(camera.K, camera.width, camera.height)
+    vis, cv, bb, fr = ctx.prepare_boxes(corners, np.linalg.inv(TrVeloToCam))
+    keep = np.arange(len(corners)) if keep_all else np.flatnonzero(vis)
+    idx_l, bb_l, fr_l = np.asarray(index)[keep].tolist(), bb[keep].tolist(), fr[keep].tolist()
+    out.cv = cv[keep]
+    for j in range(len(keep)):
+        c = out.cv[j]
+        out.append({"index": idx_l[j], "corners_velo": c, "_cv": c, "_bbox2d": bb_l[j] if fr_l[j] > 0 else None, "_front": fr_l[j]})
     return out
 
 
 def _corners_velo(bboxes_3d):
     """f64 [B,8,3] of the boxes that carry 'corners_velo' + their positions in the list."""
+    if isinstance(bboxes_3d, _PreparedBoxes) and bboxes_3d.cv is not None and len(bboxes_3d.cv) == len(bboxes_3d):
+        return bboxes_3d.cv, list(range(len(bboxes_3d)))     # (every dict of prepare_boxes carries 'corners_velo')
     pos = [i for i, b in enumerate(bboxes_3d) if "corners_velo" in b]
     if not pos:
         return np.zeros((0, 8, 3)), pos
@@ -976,25 +1014,33 @@ def _run_frames_in_mask_groups(frames, stacks, TrVeloToRect, camera, depth_max, 
 
 
 def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
-                  erode_iters=0, v3_pipeline=False, device=0, n_buffers=3, max_points=None):
+                  erode_iters=0, v3_pipeline=False, device=0, n_buffers=3, max_points=None, box_paths=None, announce=None):
     """The frame loop with read-ahead: scans are read and moved to HBM by the native reader
     (lpf_reader_*) while earlier frames are processed; yields run_frames' dict per frame.
     ``inputs_for(i, path)`` returns ``(frame_id, masks, bboxes_3d, colors)`` or None to skip the
     frame (the reference's ``continue`` rules); it runs while the scan is still being fetched.
-    A missing scan prints the reference's message (cvs_erosion.py:326-330) and is skipped."""
+    A missing scan prints the reference's message (cvs_erosion.py:326-330) and is skipped.
+    With ``box_paths`` (one ``BBoxes_<frame>.json`` per scan) the reader's worker parses the box file beside the scan
+    (lpf_reader_submit_frame) and ``inputs_for(i, path, scan)`` is called once the scan is there, ``scan.boxes_state`` /
+    ``scan.box_index`` / ``scan.boxes_cam0`` holding the result; the scans and box files of the NEXT frames are being fetched
+    meanwhile.  ``announce(i, path)`` runs before the scan is waited for (the reference's "Processing frame" line)."""
     scan_paths = [os.fspath(p) for p in scan_paths]
     if max_points is None:
         sizes = [os.path.getsize(p) // 16 for p in scan_paths if os.path.isfile(p)]
         max_points = max(sizes + [1])
     ctx = get_context(device)
-    with ScanReader(ctx, scan_paths, n_buffers=n_buffers, max_points=max_points) as reader:
+    with ScanReader(ctx, scan_paths, n_buffers=n_buffers, max_points=max_points, box_paths=box_paths) as reader:
         for i, path in enumerate(scan_paths):
-            inputs = inputs_for(i, path)
+            if announce is not None:
+                announce(i, path)
+            inputs = inputs_for(i, path) if box_paths is None else None
             try:
                 scan = next(reader)
             except RuntimeError as e:
                 print(f"Failed to load frame {os.path.basename(path)}: {e}")
                 continue
+            if box_paths is not None:
+                inputs = inputs_for(i, path, scan)
             if inputs is None:
                 continue
             frame_id, masks, boxes, colors = inputs
@@ -1014,8 +1060,22 @@ def sequence_setup(kitti360_path, seq=0, cam_id=0):
     return sequence, camera, velo_to_cam, velo_to_rect, velo
 
 
+def _boxes_of_file(json_path, camera, velo_to_cam, keep_all=False, parsed=None):
+    """load_bounding_boxes (V3:31-38) + prepare_boxes for callers that keep the boxes to themselves; None = the reference's
+    ``if not bboxes_3d_raw: continue`` (cvs_erosion.py:334-335: no file -- its message is printed -- or an empty list).  The file is
+    parsed by the library (``parsed`` = the read-ahead reader's result for it, else lpf_parse_boxes_json now); a file that is not the
+    plain schema goes through json.load as before."""
+    state, index, corners = parsed if parsed is not None else _native.parse_boxes_file(json_path)
+    if state == _native.BOXES_PARSED:
+        return prepare_boxes_from_arrays(index, corners, camera, velo_to_cam, keep_all=keep_all) if len(index) else None
+    raw = kitti360.load_bounding_boxes(json_path)           # absent: prints the reference's message, []; other schema: json.load
+    if not raw:
+        return None
+    return prepare_boxes(raw, camera, velo_to_cam, keep_all=keep_all, as_arrays=True)
+
+
 def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None,
-                         keep_all_boxes=False):
+                         keep_all_boxes=False, boxes_as_arrays=False):
     """The reference's per-frame loading + skip rules (cvs_erosion.py:320-369): a frame is
     dropped when its scan, its box file, its image or its detections are missing."""
     sequence = "2013_05_28_drive_%04d_sync" % seq
@@ -1030,10 +1090,15 @@ def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, ca
         except Exception as e:  # same breadth as the reference
             print(f"Failed to load frame {frame}: {e}")
             continue
-        raw = kitti360.load_bounding_boxes(os.path.join(bbox_dir, f"BBoxes_{frame}.json"))
-        if not raw:
-            continue
-        boxes = prepare_boxes(raw, camera, velo_to_cam, keep_all=keep_all_boxes)
+        if boxes_as_arrays:                                 # (the caller keeps the boxes to itself: the library parses the file)
+            boxes = _boxes_of_file(os.path.join(bbox_dir, f"BBoxes_{frame}.json"), camera, velo_to_cam, keep_all_boxes)
+            if boxes is None:
+                continue
+        else:
+            raw = kitti360.load_bounding_boxes(os.path.join(bbox_dir, f"BBoxes_{frame}.json"))
+            if not raw:
+                continue
+            boxes = prepare_boxes(raw, camera, velo_to_cam, keep_all=keep_all_boxes)
         image_path = os.path.join(kitti360_path, "data_2d_raw", sequence, f"image_{cam_id:02d}",
                                   "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
         if not os.path.isfile(image_path):
@@ -1062,11 +1127,13 @@ def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_
         todo = velo.available_frames() if frames is None else list(frames)
         print(f"Found {len(todo)} frames to process")
 
-        def inputs_for(i, path):
+        box_paths = [os.path.join(root, "bboxes_3D_cam0", f"BBoxes_{f}.json") for f in todo]
+
+        def inputs_for(i, path, scan):
             frame = todo[i]
-            print(f"\nProcessing frame {frame}...")
-            raw = kitti360.load_bounding_boxes(os.path.join(root, "bboxes_3D_cam0", f"BBoxes_{frame}.json"))
-            if not raw:
+            # (the box file was parsed by the reader's worker while earlier frames ran: json.load of it was most of a frame's host time)
+            boxes = _boxes_of_file(box_paths[i], camera, velo_to_cam, parsed=(scan.boxes_state, scan.box_index, scan.boxes_cam0))
+            if boxes is None:
                 return None
             image_path = os.path.join(root, "data_2d_raw", sequence, f"image_{cam_id:02d}",
                                       "data_rect" if cam_id in [0, 1] else "data_rgb", f"{frame:010d}.png")
@@ -1075,14 +1142,15 @@ def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_
             _, masks, colors, _, _ = segmenter(image_loader(image_path) if image_loader else image_path)
             if masks is None or len(masks) == 0:
                 return None
-            return frame, masks, prepare_boxes(raw, camera, velo_to_cam), colors
+            return frame, masks, boxes, colors
 
         paths = [os.path.join(velo.raw3DPcdPath, "%010d.bin" % f) for f in todo]
-        for r in stream_frames(paths, inputs_for, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
+        for r in stream_frames(paths, inputs_for, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device,
+                               box_paths=box_paths, announce=lambda i, path: print(f"\nProcessing frame {todo[i]}...")):
             if r["n_valid"] and r["car_statistics"]:
                 append_to_master_csv(r["car_statistics"], r["frame"], master_csv_path, timestamp)
         return analyze_master_csv(master_csv_path)
-    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames)
+    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames, boxes_as_arrays=True)
     for i in range(0, len(items), batch_frames):
         for r in run_frames(items[i:i + batch_frames], velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
             if r["n_valid"] == 0:

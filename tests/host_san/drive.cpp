@@ -290,21 +290,106 @@ static void reader(const char *tmpdir)
         }
         paths.push_back(p);
     }
+    // the frames' box files ride along: scan i has i boxes (file 3 is absent, file 5 has a key the schema lacks, file 6 is cut short)
+    std::vector<std::string> bpaths;
+    for (int i = 0; i < 12; ++i) {
+        std::string p = std::string(tmpdir) + "/BBoxes_" + std::to_string(i) + ".json";
+        if (i != 3) {
+            std::string t = "[";
+            for (int b = 0; b < i; ++b) {
+                t += std::string(b ? ",\n " : "") + "{\"index\": " + std::to_string(100 * i + b) + ", \"corners_cam0\": [";
+                for (int k = 0; k < 8; ++k) t += std::string(k ? ", " : "") + "[" + std::to_string(i) + ".5, -" + std::to_string(b) + "e-1, " + std::to_string(k) + "]";
+                t += i == 5 ? "], \"label\": 1}" : "]}";
+            }
+            t += "]";
+            if (i == 6) t.resize(t.size() / 2);
+            FILE *f = fopen(p.c_str(), "wb");
+            fwrite(t.data(), 1, t.size(), f);
+            fclose(f);
+        }
+        bpaths.push_back(p);
+    }
     lpf_reader *rd = nullptr;
     CHECK(lpf_reader_create(c, &rd, 1, 1000) == LPF_ERR_ARG);
     CHECK(lpf_reader_create(c, &rd, 3, 600) == LPF_OK && rd);
-    for (auto &p : paths) CHECK(lpf_reader_submit(rd, p.c_str()) == LPF_OK);
+    {
+        int nb = -1, st = -1;
+        CHECK(lpf_reader_boxes(rd, nullptr, nullptr, &nb, &st) == LPF_ERR_STATE);                // nothing handed out yet
+    }
+    for (int i = 0; i < 12; ++i) CHECK(lpf_reader_submit_frame(rd, paths[(size_t)i].c_str(), i == 11 ? nullptr : bpaths[(size_t)i].c_str()) == LPF_OK);
     for (int i = 0; i < 12; ++i) {
         const float *d = nullptr, *h = nullptr;
         int64_t n = 0;
         const int rc = lpf_reader_next(rd, &d, &h, &n);
         if (i == 4 || i == 7 || 100 + 37 * i > 600) CHECK(rc == LPF_ERR_IO);
         else { CHECK(rc == LPF_OK && n == 100 + 37 * i && h && d && h[0] == (float)i && d[4 * n - 1] == (float)i); CHECK(lpf_reader_wait(rd) == LPF_OK); }
+        const double *bc = nullptr; const int32_t *bi = nullptr;
+        int nb = -1, st = -1;
+        CHECK(lpf_reader_boxes(rd, &bc, &bi, &nb, &st) == LPF_OK);                                 // (a failed scan still has its box file)
+        if (i == 11) CHECK(st == LPF_BOXES_NONE && nb == 0 && !bc);
+        else if (i == 3) CHECK(st == LPF_BOXES_ABSENT && nb == 0);
+        else if (i == 5 || i == 6) CHECK(st == LPF_BOXES_OTHER && nb == 0 && !bc && !bi);
+        else {
+            CHECK(st == LPF_BOXES_PARSED && nb == i);
+            for (int b = 0; b < nb; ++b)
+                CHECK(bi[b] == 100 * i + b && bc[24 * b] == i + 0.5 && bc[24 * b + 1] == -(double)b / 10.0 && bc[24 * b + 23] == 7.0);
+        }
     }
     for (int i = 0; i < 3; ++i) CHECK(lpf_reader_submit(rd, paths[i].c_str()) == LPF_OK);      // destroyed with scans still queued
     lpf_reader_destroy(rd);
     lpf_destroy(c);
     g_ctx = nullptr;
+}
+
+// lpf_parse_boxes_json on every prefix of a file and on a few thousand damaged copies of it: whatever the bytes, the parser stays inside
+// its buffer (ASan) and either parses or says OTHER
+static void box_files(const char *tmpdir)
+{
+    std::string good = "[";
+    for (int b = 0; b < 3; ++b) {
+        good += std::string(b ? ", " : "") + "{\"index\": " + std::to_string(b - 1) + ", \"corners_cam0\": [";
+        for (int k = 0; k < 8; ++k) good += std::string(k ? "," : "") + "[-1.25e1, 2, 0.30000000000000004]";
+        good += "]}";
+    }
+    good += "]\n";
+    const std::string p = std::string(tmpdir) + "/BBoxes_fuzz.json";
+    auto run = [&](const std::string &text, int &nb, int &st, double *cs, int32_t *ix, int cap) {
+        FILE *f = fopen(p.c_str(), "wb");
+        fwrite(text.data(), 1, text.size(), f);
+        fclose(f);
+        return lpf_parse_boxes_json(p.c_str(), cs, ix, cap, &nb, &st);
+    };
+    double cs[4 * 24]; int32_t ix[4];
+    int nb = -1, st = -1;
+    CHECK(run(good, nb, st, cs, ix, 4) == LPF_OK && st == LPF_BOXES_PARSED && nb == 3 && ix[0] == -1 && ix[2] == 1 && cs[0] == -12.5 && cs[71] == 0.30000000000000004);
+    CHECK(run(good, nb, st, cs, ix, 2) == LPF_ERR_ARG && nb == 3);
+    CHECK(run(good, nb, st, nullptr, nullptr, 0) == LPF_ERR_ARG && nb == 3);
+    for (size_t k = 0; k + 2 < good.size(); ++k) CHECK(run(good.substr(0, k), nb, st, cs, ix, 4) == LPF_OK && st == LPF_BOXES_OTHER && nb == 0);
+    uint32_t x = 12345;
+    auto rnd = [&x] { x = x * 1664525u + 1013904223u; return x >> 8; };
+    int parsed = 0;
+    for (int it = 0; it < 4000; ++it) {
+        std::string t = good;
+        const int edits = 1 + (int)(rnd() % 3);
+        for (int e = 0; e < edits; ++e) {
+            const size_t at = rnd() % t.size();
+            switch (rnd() % 4) {
+            case 0: t[at] = (char)(rnd() & 0xff); break;
+            case 1: t.erase(at, 1 + rnd() % 4); break;
+            case 2: t.insert(at, 1, "0123456789.eE+-[]{},:\" \n"[rnd() % 24]); break;
+            default: t[at] = "0123456789.eE+-[]{},:\" \n"[rnd() % 24]; break;
+            }
+            if (t.empty()) t = " ";
+        }
+        const int rc = run(t, nb, st, cs, ix, 4);
+        CHECK((rc == LPF_OK && (st == LPF_BOXES_OTHER || (st == LPF_BOXES_PARSED && nb <= 4))) || (rc == LPF_ERR_ARG && nb > 4));
+        parsed += st == LPF_BOXES_PARSED;
+    }
+    CHECK(parsed > 0 && parsed < 4000);                                   // (a changed digit still parses; a lost bracket does not)
+    remove(p.c_str());
+    CHECK(run("", nb, st, cs, ix, 4) == LPF_OK && st == LPF_BOXES_OTHER);
+    remove(p.c_str());
+    CHECK(lpf_parse_boxes_json(p.c_str(), cs, ix, 4, &nb, &st) == LPF_OK && st == LPF_BOXES_ABSENT);
 }
 
 int main(int argc, char **argv)
@@ -321,6 +406,7 @@ int main(int argc, char **argv)
     pipelined_streams(0, runs / 8, 1408, 376);               // in order: the candidate grid goes ahead of the tiles as a kernel
     graphs();
     reader(tmp);
+    box_files(tmp);
     fprintf(stderr, "drive: %d failed checks, %lld fake launches\n", g_fail, fake_hip_launches());
     return g_fail ? 1 : 0;
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_native.EXPORTED) == names
     lib.lpf_abi_version.restype = ctypes.c_int
-    assert lib.lpf_abi_version() == 7
+    assert lib.lpf_abi_version() == 8
     # the measured-slower machinery of ABI 4 is gone from the product, and the geometry override lives in the lab build only
     assert not hasattr(lib, "lpf_set_cu_partition") and not hasattr(lib, "lpf_set_geometry") and not hasattr(lib, "lpf_lab_role_clock")
     assert _declared(lab=True) == sorted(names + ["lpf_set_geometry", "lpf_lab_role_clock"])

@@ -160,8 +160,16 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
         if "skipped" in r:
             continue                                                     # 2717: no BBoxes json -> frame dropped
         raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
-        (root / "bboxes_3D_cam0" / ("BBoxes_%d.json" % r["frame"])).write_text(json.dumps(raw))
+        if r["frame"] == 250:                                            # a key beyond the plain schema: the library's parser leaves this
+            for b in raw:                                                # file to json.load (lpf_parse_boxes_json: OTHER), same rows
+                b["label"] = "car"
+        (root / "bboxes_3D_cam0" / ("BBoxes_%d.json" % r["frame"])).write_text(json.dumps(raw, indent=2 if r["frame"] == 570 else None))
         masks_of[r["frame"]] = unpack_masks(g, "rect5", cam.height, cam.width)
+        if r["frame"] == 570:                                            # ... and a frame whose box file is an empty list: skipped (cvs:334-335)
+            g["points"].tofile(str(root / "data_3d_raw" / seq / "velodyne_points" / "data" / ("%010d.bin" % 571)))
+            (root / "data_2d_raw" / seq / "image_00" / "data_rect" / ("%010d.png" % 571)).write_bytes(b"")
+            (root / "bboxes_3D_cam0" / "BBoxes_571.json").write_text("[]")
+            masks_of[571] = masks_of[570]
         for i in range(len(g["stats_car_id_rect5_d50"])):
             expect.append((r["frame"], int(g["stats_car_id_rect5_d50"][i]), int(g["stats_matched_bbox_id_rect5_d50"][i]),
                            int(g["stats_total_points_rect5_d50"][i]), int(g["stats_points_inside_bbox_rect5_d50"][i])))
@@ -182,14 +190,40 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
            zip(df["frame"], df["car_id"], df["matched_bbox_id"], df["total_points"], df["points_inside_bbox"])]
     assert got == expect and len(expect) > 5
     text = out.getvalue()
-    assert "Found 5 frames to process" in text and "No bounding boxes found" in text and "OVERALL ANALYSIS" in text
+    assert "Found 6 frames to process" in text and "No bounding boxes found" in text and "OVERALL ANALYSIS" in text
     # the same run frame by frame with the native read-ahead scan reader: same rows, same file
     csv2 = str(tmp_path / "results2" / "master_car_statistics.csv")
     with contextlib.redirect_stdout(io.StringIO()) as out2:
         df2 = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root),
                                       master_csv_path=csv2, timestamp="T", read_ahead=True)
     assert open(csv2).read() == open(csv_path).read() and df2.equals(df)
-    assert "Found 5 frames to process" in out2.getvalue() and "OVERALL ANALYSIS" in out2.getvalue()
+    assert "Found 6 frames to process" in out2.getvalue() and "OVERALL ANALYSIS" in out2.getvalue()
+    assert "No bounding boxes found" in out2.getvalue() and sorted(out2.getvalue().splitlines()) == sorted(text.splitlines())   # the same lines
+
+
+def test_boxes_parsed_by_the_library_equal_the_json_path(calib, tmp_path):
+    """prepare_boxes_from_arrays (box file parsed by lpf_parse_boxes_json / the reader's worker) against prepare_boxes on json.load's
+    dicts: the same visible boxes in the same order, the same corners bit for bit, the same 2D boxes."""
+    from lidar_object_detection_amd import _native
+    cam = _camera(calib)
+    for frame in (100, 2449):
+        g = load_golden(frame)
+        raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
+        p = tmp_path / ("BBoxes_%d.json" % frame)
+        p.write_text(json.dumps(raw))
+        st, idx, cs = _native.parse_boxes_file(str(p))
+        assert st == _native.BOXES_PARSED
+        for keep_all in (False, True):
+            a = pipeline.prepare_boxes_from_arrays(idx, cs, cam, calib["TrVeloToCam"], keep_all=keep_all)
+            b = pipeline.prepare_boxes(json.load(open(p)), cam, calib["TrVeloToCam"], keep_all=keep_all)
+            assert len(a) == len(b) > 0 and [d["index"] for d in a] == [d["index"] for d in b]
+            assert np.array_equal(np.array([d["corners_velo"] for d in a]), np.array([d["corners_velo"] for d in b]))
+            assert [d["_bbox2d"] for d in a] == [d["_bbox2d"] for d in b] and [d["_front"] for d in a] == [d["_front"] for d in b]
+            ca, pa = pipeline._corners_velo(a)
+            cb, pb = pipeline._corners_velo(b)
+            assert np.array_equal(ca, cb) and pa == pb == list(range(len(a)))
+            assert np.array_equal(pipeline._corners_velo(list(b))[0], cb)            # (a plain list of the same dicts: the walk gives the same)
+    assert pipeline._boxes_of_file(str(tmp_path / "BBoxes_none.json"), cam, calib["TrVeloToCam"]) is None
 
 
 @pytest.mark.parametrize("rec", FRAMES, ids=lambda r: "f%d" % r["frame"])

@@ -64,6 +64,15 @@ def main():
         t_batch, df = min((run(False, k) for k in range(1, 4)), key=lambda t: t[0])
         t_ahead, df2 = min((run(True, k) for k in range(1, 4)), key=lambda t: t[0])
         assert df.equals(df2) and len(df) > 50
+        if os.environ.get("PROFILE_PROCESS_FRAMES") in ("batched", "read_ahead"):          # where the host's time goes (stderr)
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for k in range(4, 9):
+                run(os.environ["PROFILE_PROCESS_FRAMES"] == "read_ahead", k)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(32)
         # the reference's statements for the same frames, on the host
         t0 = time.perf_counter()
         rows = 0
