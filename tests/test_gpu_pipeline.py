@@ -198,7 +198,7 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
                                       master_csv_path=csv2, timestamp="T", read_ahead=True)
     assert open(csv2).read() == open(csv_path).read() and df2.equals(df)
     assert "Found 6 frames to process" in out2.getvalue() and "OVERALL ANALYSIS" in out2.getvalue()
-    assert "No bounding boxes found" in out2.getvalue() and sorted(out2.getvalue().splitlines()) == sorted(text.splitlines())   # the same lines
+    assert "No bounding boxes found" in out2.getvalue() and sorted(out2.getvalue().replace("results2", "results").splitlines()) == sorted(text.splitlines())   # the same lines
 
 
 def test_boxes_parsed_by_the_library_equal_the_json_path(calib, tmp_path):
