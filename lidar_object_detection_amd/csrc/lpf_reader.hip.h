@@ -115,7 +115,9 @@ bool box_number(BoxCur &c, double &v)
     if (n < sizeof small) { memcpy(small, b, n); small[n] = 0; z = small; }
     else { big.assign(b, n); z = big.c_str(); }
     char *end = nullptr;
-    v = strtod_l(z, &end, box_c_locale());
+    const locale_t loc = box_c_locale();
+    if (!loc) return false;                 // (no "C" locale object to be had: nothing is interpreted, the caller's json.load does it)
+    v = strtod_l(z, &end, loc);
     if (end != z + n) return false;
     if (integral) {                         // json.load makes an int of it, and the float64 array a double of that int: "-0" is +0.0 there,
         if (v == 0.0) v = 0.0;              // and an integer beyond the doubles' range raises OverflowError instead of becoming inf
