@@ -559,7 +559,50 @@ def secondary_lines(torch, dev, local_rank, T, K, W, H, use_rects=True):
             "includes": "H2D of points + masks + box corners (pinned), box table set-up, mask pack + erosion, project+label, lists + box counts, "
                         "finalize, D2H of counts + summary",
             "checked": "n_valid, inst_count, count_mb, best_box of the first 4 frames == CPU oracle"}
+
+    # ---- the reference-shaped entry points (what a user of the scripts calls): run_frames on sample frame 100, process_frames over files -------
+    if os.path.exists(gpath):
+        try:
+            out["entry_points"] = entry_point_lines(torch, dev, local_rank, gdir)
+        except AssertionError as e:                       # a wrong row is a failed bench, like every other check of this file
+            raise SystemExit("bench entry points: %s" % e)
     return out
+
+
+def entry_point_lines(torch, dev, local_rank, gdir):
+    """cvs_erosion.py's frame step as the package's run_frames (dicts of the reference's keys out) on sample frame 100, and
+    process_frames (cvs:298-379: files -> master CSV) over 20 real frames -- wall time per call / per frame on this host, results checked
+    against the reference-generated golden vectors."""
+    from lidar_object_detection_amd import pipeline
+    cal = np.load(os.path.join(gdir, "calib_cam0.npz"))
+    g = np.load(os.path.join(gdir, "frame_0000000100.npz"))
+    W, H = int(cal["width"]), int(cal["height"])
+    T = np.asarray(cal["TrVeloToRect"])
+    cam = type("Cam", (), {"K": np.asarray(cal["K"]), "width": W, "height": H})()
+    pts = np.ascontiguousarray(g["points"], dtype=np.float32)
+    masks = np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :W].astype(np.float32)          # YOLO's masks: float32 0 / 1 (V3:72)
+    boxes3d = [{"corners_velo": c.tolist()} for c in g["corners_velo"]]
+    colors = pipeline.default_colors(len(masks))
+    want = g["stats_points_inside_bbox_rect5_d50"].tolist()
+    d_masks, d_pts = torch.from_numpy(masks).to(dev), torch.from_numpy(pts).to(dev)
+    res = {}
+    for name, p_, m_ in (("host_points_host_masks", pts, masks), ("host_points_masks_on_gpu", pts, d_masks), ("points_and_masks_on_gpu", d_pts, d_masks)):
+        item = pipeline.FrameInputs(100, p_, m_, boxes3d, colors)
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            r = pipeline.run_frames([item], T, cam, 50.0, 10, True, device=local_rank)[0]
+            ts.append(time.perf_counter() - t0)
+        assert [d["points_inside_bbox"] for d in r["car_statistics"]] == want and np.array_equal(r["valid_indices"], g["valid_idx_d50"]), "run_frames(%s)" % name
+        res[name] = round(1e3 * float(np.median(ts[8:])), 4)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import process_frames_bench
+    pf = process_frames_bench.measure(reference_too=False)
+    return {"run_frames_frame100_ms_per_call_p50": res,
+            "run_frames_checked": "car_statistics.points_inside_bbox and valid_indices == tests/golden/frame_0000000100.npz (reference functions)",
+            "process_frames_20_real_frames_ms_per_frame": {"batched": pf["ms_per_frame"]["batched"], "read_ahead": pf["ms_per_frame"]["read_ahead"]},
+            "process_frames_checked": pf["checked"], "process_frames_note": pf["note"]}
 
 
 def check_frames(torch, out, pts_dev_b, scenes, velo_per_frame, keep_per_frame, n, T, K, W, H, dmax, what):

@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def measure(profile=None, reference_too=True):
+    """dict of the timings (see the module docstring); ``profile`` = "batched" / "read_ahead": cProfile of five runs to stderr."""
     import torch  # noqa: F401
     from conftest import load_calib
     from lidar_object_detection_amd import kitti360, pipeline
@@ -46,7 +47,10 @@ def main():
                 masks_of[fr] = np.unpackbits(g["masks_rect5_packed"], axis=-1)[..., :W].astype(np.float32)
                 frames.append(fr)
         velo = kitti360.Kitti360Viewer3DRaw(seq=0, root_dir=root)
-        pipeline.sequence_setup = lambda path, s=0, c=0: (seq, cam, calib["TrVeloToCam"], calib["TrVeloToRect"], velo)
+        real_setup = pipeline.sequence_setup           # (the tree has no calibration files: the set-up comes from the fixture; put back below)
+
+        def patched_setup(path, s=0, c=0):
+            return seq, cam, calib["TrVeloToCam"], calib["TrVeloToRect"], velo
 
         def segmenter(image_path):
             m = masks_of[int(os.path.basename(image_path).split(".")[0])]
@@ -56,27 +60,40 @@ def main():
             csv = os.path.join(tmp, "results_%d_%d" % (read_ahead, k), "master.csv")
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                df = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=root, master_csv_path=csv,
-                                             timestamp="T", read_ahead=read_ahead)
+                pipeline.sequence_setup = patched_setup
+                try:
+                    df = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=root, master_csv_path=csv,
+                                                 timestamp="T", read_ahead=read_ahead)
+                finally:
+                    pipeline.sequence_setup = real_setup
             return time.perf_counter() - t0, df
 
         run(False, 0)                                       # warm (allocations)
         t_batch, df = min((run(False, k) for k in range(1, 4)), key=lambda t: t[0])
         t_ahead, df2 = min((run(True, k) for k in range(1, 4)), key=lambda t: t[0])
         assert df.equals(df2) and len(df) > 50
-        if os.environ.get("PROFILE_PROCESS_FRAMES") in ("batched", "read_ahead"):          # where the host's time goes (stderr)
+        if profile in ("batched", "read_ahead"):          # where the host's time goes (stderr)
             import cProfile
             import pstats
             pr = cProfile.Profile()
             pr.enable()
             for k in range(4, 9):
-                run(os.environ["PROFILE_PROCESS_FRAMES"] == "read_ahead", k)
+                run(profile == "read_ahead", k)
             pr.disable()
             pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(32)
+        # the rows are the reference's: per frame, the golden statistics of its scan (five copies of four frames, in frame order)
+        want = []
+        for fr in sorted(frames):
+            g = np.load(os.path.join(gdir, {100: "frame_0000000100.npz", 1461: "frame_0000001461_full.npz", 2098: "frame_0000002098_full.npz",
+                                            2449: "frame_0000002449_full.npz"}[fr % 10000]))
+            want += [(fr, int(a), int(b), int(c), int(d)) for a, b, c, d in zip(g["stats_car_id_rect5_d50"], g["stats_matched_bbox_id_rect5_d50"],
+                                                                             g["stats_total_points_rect5_d50"], g["stats_points_inside_bbox_rect5_d50"])]
+        got = [(int(a), int(b), int(c), int(d), int(e)) for a, b, c, d, e in zip(df["frame"], df["car_id"], df["matched_bbox_id"], df["total_points"], df["points_inside_bbox"])]
+        assert got == want, "process_frames: the CSV rows differ from the reference-generated golden statistics"
         # the reference's statements for the same frames, on the host
         t0 = time.perf_counter()
         rows = 0
-        for fr in sorted(frames):
+        for fr in (sorted(frames) if reference_too else []):
             pts = velo.loadVelodyneData(fr)
             raw = kitti360.load_bounding_boxes(os.path.join(root, "bboxes_3D_cam0", "BBoxes_%d.json" % fr))
             camc = np.array([b["corners_cam0"] for b in raw], np.float64)
@@ -85,13 +102,18 @@ def main():
             rows += int((out[6] > 0).sum())
         t_ref = time.perf_counter() - t0
         npts = sum(os.path.getsize(os.path.join(root, "data_3d_raw", seq, "velodyne_points", "data", "%010d.bin" % fr)) // 16 for fr in frames)
-        print(json.dumps({"workload": "process_frames over 20 real frames (%d points, 5 masks each, 21...314 annotated boxes per frame), files -> CSV" % npts,
-                          "process_frames_batched_ms": round(1e3 * t_batch, 2), "process_frames_read_ahead_ms": round(1e3 * t_ahead, 2),
-                          "reference_numpy_statements_ms": round(1e3 * t_ref, 2), "csv_rows": int(len(df)),
-                          "ms_per_frame": {"batched": round(1e3 * t_batch / 20, 3), "read_ahead": round(1e3 * t_ahead / 20, 3),
-                                           "reference_numpy": round(1e3 * t_ref / 20, 3)},
-                          "note": "both sides read the scans and box files and parse the JSON; the package's side also writes the CSV and prints "
-                                  "the analysis; masks are float32 host arrays (10.6 MB per frame cross PCIe in the package's path)"}))
+        return {"workload": "process_frames over 20 real frames (%d points, 5 masks each, 21...314 annotated boxes per frame), files -> CSV" % npts,
+                "process_frames_batched_ms": round(1e3 * t_batch, 2), "process_frames_read_ahead_ms": round(1e3 * t_ahead, 2),
+                "reference_numpy_statements_ms": round(1e3 * t_ref, 2) if reference_too else None, "csv_rows": int(len(df)),
+                "ms_per_frame": {"batched": round(1e3 * t_batch / 20, 3), "read_ahead": round(1e3 * t_ahead / 20, 3),
+                                 "reference_numpy": round(1e3 * t_ref / 20, 3) if reference_too else None},
+                "checked": "every CSV row (frame, car_id, matched_bbox_id, total_points, points_inside_bbox) == the reference-generated golden statistics; both modes write the same file",
+                "note": "both sides read the scans and box files and parse the JSON; the package's side also writes the CSV and prints "
+                        "the analysis; masks are float32 host arrays (10.6 MB per frame cross PCIe in the package's path)"}
+
+
+def main():
+    print(json.dumps(measure(os.environ.get("PROFILE_PROCESS_FRAMES"))))
 
 
 if __name__ == "__main__":
