@@ -796,6 +796,19 @@ def default_colors(n):
     return [(int(i * 60) % 255, int(i * 120) % 255, int(i * 180) % 255) for i in range(n)]
 
 
+class _LiveScanPoints:
+    """The pinned points of a reader's Scan for the lazy gathers: indexable like the array while the scan is the reader's current one,
+    an LpfError afterwards (its buffers hold another scan by then)."""
+    __slots__ = ("scan",)
+
+    def __init__(self, scan):
+        self.scan = scan
+
+    def __getitem__(self, key):
+        self.scan._check_live()
+        return self.scan.points[key]
+
+
 class FrameResult(dict):
     """run_frames' dict of one frame.  The integers the kernels produced (valid_indices, count_mb, car_statistics, n_valid) are there
     at once; the arrays of the reference's types that are GATHERS or CASTS of them -- ``points_valid`` (V3:592), ``car_point_sets``
@@ -904,12 +917,14 @@ def _host_masks_to_device_batch(stacks, M, H, W, ctx):
 
 
 def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
-               erode_iters=0, v3_pipeline=False, device=0, ctx=None):
+               erode_iters=0, v3_pipeline=False, device=0, ctx=None, gather_scans=True):
     """Projection + clip + mask lookup + box counting + best-box scan for a list of
     FrameInputs in ONE batched call (frames are independent units).  Returns one dict per
     frame: valid_indices, u_valid, v_valid, points_valid, car_point_sets, bg_assigned,
     count_mb, car_statistics (cvs_erosion key set) -- the integers are the kernels' output,
-    the dicts are assembled here."""
+    the dicts are assembled here.  Frames whose points are a read-ahead reader's ``Scan`` have their gathers (``points_valid``,
+    ``car_point_sets``) made before the call returns, because the reader recycles the scan's buffers when it moves on;
+    ``gather_scans=False`` leaves them lazy like everyone else's -- reading them after the reader has moved on raises."""
     if not frames:
         return []
     ctx = ctx or get_context(device)
@@ -972,7 +987,7 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         labv = r["label_valid"].copy()
         lists = [l.copy() for l in r["inst_lists"][:m]]
         is_scan = isinstance(f.points, Scan)
-        host_pts = f.points.points if is_scan else f.points              # Scan: pinned copy of the file
+        host_pts = _LiveScanPoints(f.points) if is_scan else f.points    # Scan: pinned copy of the file, while the reader has not moved on
         if _is_device_tensor(host_pts):                                  # points that live on the GPU: the gathers run there when asked for
             host_pts = _DevicePoints(host_pts)
         stats = []
@@ -985,7 +1000,7 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
                     car_point_sets=lambda p=host_pts, ls=lists: [p[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in ls],
                     bg_assigned=lambda labv=labv: labv != 0)
         fr = FrameResult(dict(frame=f.frame, valid_indices=vi, count_mb=r["count_mb"][:m].copy(), car_statistics=stats, n_valid=r["n_valid"]), lazy)
-        if is_scan:
+        if is_scan and gather_scans:
             fr._all()                                        # (a Scan's pinned points are recycled when the reader moves on: gather now)
         out.append(fr)
     return out
@@ -1014,7 +1029,7 @@ def _run_frames_in_mask_groups(frames, stacks, TrVeloToRect, camera, depth_max, 
 
 
 def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_oriented=True,
-                  erode_iters=0, v3_pipeline=False, device=0, n_buffers=3, max_points=None, box_paths=None, announce=None):
+                  erode_iters=0, v3_pipeline=False, device=0, n_buffers=3, max_points=None, box_paths=None, announce=None, gather=True):
     """The frame loop with read-ahead: scans are read and moved to HBM by the native reader
     (lpf_reader_*) while earlier frames are processed; yields run_frames' dict per frame.
     ``inputs_for(i, path)`` returns ``(frame_id, masks, bboxes_3d, colors)`` or None to skip the
@@ -1023,7 +1038,9 @@ def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, 
     With ``box_paths`` (one ``BBoxes_<frame>.json`` per scan) the reader's worker parses the box file beside the scan
     (lpf_reader_submit_frame) and ``inputs_for(i, path, scan)`` is called once the scan is there, ``scan.boxes_state`` /
     ``scan.box_index`` / ``scan.boxes_cam0`` holding the result; the scans and box files of the NEXT frames are being fetched
-    meanwhile.  ``announce(i, path)`` runs before the scan is waited for (the reference's "Processing frame" line)."""
+    meanwhile.  ``announce(i, path)`` runs before the scan is waited for (the reference's "Processing frame" line).
+    ``gather=False``: the consumer only reads the statistics (process_frames writes the CSV): ``points_valid`` / ``car_point_sets``
+    are not gathered from the scan before the reader recycles it (run_frames' ``gather_scans``)."""
     scan_paths = [os.fspath(p) for p in scan_paths]
     if max_points is None:
         sizes = [os.path.getsize(p) // 16 for p in scan_paths if os.path.isfile(p)]
@@ -1045,7 +1062,7 @@ def stream_frames(scan_paths, inputs_for, TrVeloToRect, camera, depth_max=50.0, 
                 continue
             frame_id, masks, boxes, colors = inputs
             yield run_frames([FrameInputs(frame_id, scan, masks, boxes, colors)], TrVeloToRect, camera, depth_max,
-                             min_points, use_oriented, erode_iters, v3_pipeline, device, ctx)[0]
+                             min_points, use_oriented, erode_iters, v3_pipeline, device, ctx, gather_scans=gather)[0]
 
 
 # ---------------------------------------------------------------------------------------
@@ -1146,7 +1163,7 @@ def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_
 
         paths = [os.path.join(velo.raw3DPcdPath, "%010d.bin" % f) for f in todo]
         for r in stream_frames(paths, inputs_for, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device,
-                               box_paths=box_paths, announce=lambda i, path: print(f"\nProcessing frame {todo[i]}...")):
+                               box_paths=box_paths, announce=lambda i, path: print(f"\nProcessing frame {todo[i]}..."), gather=False):
             if r["n_valid"] and r["car_statistics"]:
                 append_to_master_csv(r["car_statistics"], r["frame"], master_csv_path, timestamp)
         return analyze_master_csv(master_csv_path)
