@@ -162,3 +162,28 @@ def test_absent_file_and_capacity(tmp_path):
     rc = lib.lpf_parse_boxes_json(p.encode(), cs.ctypes.data, ix.ctypes.data, 2, ctypes.byref(n), ctypes.byref(state))
     assert rc == -1 and n.value == 3 and state.value == _native.BOXES_PARSED and not cs.any()      # LPF_ERR_ARG, nothing written
     assert lib.lpf_parse_boxes_json(None, None, None, 0, ctypes.byref(n), ctypes.byref(state)) == -1
+
+
+def test_integration_md_box_file_snippet_runs(tmp_path, capsys):
+    """The box-file snippet of INTEGRATION.md section C, executed as written through raw ctypes: a plain file, a file with another key
+    (json.load's result), an absent file (the reference's message) and an empty list."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## C. Raw ctypes stub"):]
+    code = [b for b in re.findall(r"```python\n(.*?)```", sec, re.S) if "lpf_parse_boxes_json" in b][0]
+    lib = ctypes.CDLL(_native.library_path())
+    ns = {"ctypes": ctypes, "np": np, "os": os, "json": json, "lib": lib, "P": ctypes.c_void_p}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    load = ns["load_bounding_boxes_cam0"]
+    g = np.load(os.path.join(GOLDEN, "frame_0000000100.npz"))
+    raw = [{"index": int(i), "corners_cam0": c.tolist()} for i, c in zip(g["box_index_raw"], g["corners_cam0_raw"])]
+    idx, cs = load(_write(tmp_path, json.dumps(raw)))
+    assert idx.tolist() == g["box_index_raw"].tolist() and np.array_equal(_bits(cs), _bits(g["corners_cam0_raw"]))
+    for b in raw:
+        b["label"] = "car"
+    idx2, cs2 = load(_write(tmp_path, json.dumps(raw), "BBoxes_2.json"))
+    assert idx2.tolist() == idx.tolist() and np.array_equal(_bits(cs2), _bits(cs))
+    assert load(_write(tmp_path, "[]", "BBoxes_3.json")) is None
+    capsys.readouterr()
+    assert load(str(tmp_path / "BBoxes_4.json")) is None and "No bounding boxes found" in capsys.readouterr().out
