@@ -2091,13 +2091,14 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_box_job_kernel(const LpfBoxJob 
 __device__ __forceinline__ unsigned lpf_rect_keep16(const int4 r, const int y, const int x, const int W)
 {
     const int n0 = min(16, W - x);                          // pixels of the group on row y
+    const int rx0 = max(r.x, 0), rx1 = min(r.z, W);         // (clipped to the image first: INT_MAX as "no limit" must not overflow below)
     unsigned k = 0u;
     if (y >= r.y && y < r.w) {
-        const int lo = max(r.x - x, 0), hi = min(r.z - x, n0);
+        const int lo = max(rx0 - x, 0), hi = min(rx1 - x, n0);
         if (hi > lo) k = (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
     }
     if (n0 < 16 && y + 1 >= r.y && y + 1 < r.w) {           // (W not a multiple of 16: pixel i >= n0 is column i - n0 of the next row)
-        const int lo = max(r.x + n0, n0), hi = min(r.z + n0, 16);
+        const int lo = rx0 + n0, hi = min(rx1 + n0, 16);
         if (hi > lo) k |= (0xFFFFu >> (16 - hi)) & (0xFFFFu << lo);
     }
     return k & 0xFFFFu;

@@ -202,3 +202,72 @@ def test_hint_is_ignored_where_masks_are_not_packed_as_they_are(calib):
             ref[hint] = out
         for a, b in zip(ref[False], ref[True]):
             assert np.array_equal(a, b) and a.any()
+
+
+@pytest.mark.parametrize("mode", [False, "fused-pack"])
+@pytest.mark.parametrize("cam", ["kitti_1242x375", "narrow_1000x37", "tiny_17x16"])
+def test_cameras_whose_size_is_no_multiple_of_the_grid_cell_and_rectangles_beyond_the_image(mode, cam):
+    """The candidate grid of the rectangle-reading tiles has 16 x 16-pixel cells and the pack works in groups of 16 pixels: cameras whose
+    width / height are no multiple of 16 (KITTI's 1242 x 375; a 37-row strip; 17 x 16, one cell and one pixel), and rectangles that
+    start left of / above the image or end beyond it (read as clipped to the image), in a LARGE launch of sparse frames (the grid form)
+    and a small one (all mask bytes gated by the rectangles)."""
+    import torch
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, SUMMARY_DTYPE
+    W, H = {"kitti_1242x375": (1242, 375), "narrow_1000x37": (1000, 37), "tiny_17x16": (17, 16)}[cam]
+    _, T, K0, W0, H0 = S.default_calibration(None)
+    K = np.array(K0, dtype=np.float64).copy()
+    K[0, 0] *= W / W0; K[0, 2] *= W / W0; K[1, 1] *= H / H0; K[1, 2] *= H / H0           # the same field of view on the other sensor
+    dev = torch.device("cuda", 0)
+    M = 6
+    for F, n in ((18, 230_000), (2, 50_000)):                                          # > 3.5 Mi points: the large geometry; a small launch
+        rng = np.random.default_rng(W * 31 + F)
+        clouds = [S.synthetic_cloud(n + 131 * f, seed=9100 + f) for f in range(F)]
+        masks = (rng.random((F, M, H, W)) < 0.4).astype(np.uint8)
+        rects = np.zeros((F, M, 4), np.int32)
+        for f in range(F):
+            for m in range(M):
+                x0, y0 = rng.integers(-20, W - 1), rng.integers(-20, H - 1)
+                rects[f, m] = (x0, y0, rng.integers(x0 + 1, W + 30), rng.integers(y0 + 1, H + 30))
+        rects[0, 0] = (-7, -3, W + 9, H + 4); rects[0, 1] = (W - 1, H - 1, W + 100, H + 100); rects[0, 2] = (-50, -50, 1, 1)
+        rects[0, 3] = (W, 0, W + 5, H); rects[0, 4] = (0, H, W, H + 5); rects[0, 5] = (-9, -9, 0, 0)      # (the last three: wholly outside)
+        big = np.iinfo(np.int32)
+        rects[1, 0] = (big.min, big.min, big.max, big.max)                 # "no limit" sentinels: the whole image,
+        rects[1, 1] = (W - 3, big.min, big.max, big.max)                   # ... its last three columns,
+        rects[1, 2] = (big.min, H - 2, big.max, big.max)                   # ... its last two rows
+        clipped = rects.copy()
+        clipped[..., 0] = np.clip(rects[..., 0], 0, W); clipped[..., 2] = np.clip(rects[..., 2], 0, W)
+        clipped[..., 1] = np.clip(rects[..., 1], 0, H); clipped[..., 3] = np.clip(rects[..., 3], 0, H)
+        expect = _outside_zeroed(masks, clipped)
+        assert expect[0, 0].any() and not expect[0, 3].any() and not expect[0, 4].any() and not expect[0, 5].any()
+        sizes = [len(c) for c in clouds]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ntot, cap = int(off[-1]), max(sizes)
+        d_pts = torch.from_numpy(np.concatenate(clouds)).to(dev)
+        d_masks, d_rects = torch.from_numpy(masks).to(dev), torch.from_numpy(rects).to(dev)
+        o = dict(uv=torch.empty((ntot, 2), dtype=torch.int32, device=dev), label_bits=torch.empty(ntot, dtype=torch.int32, device=dev),
+                 valid_idx=torch.empty(ntot, dtype=torch.int64, device=dev), inst_idx=torch.empty((F, cap), dtype=torch.int64, device=dev),
+                 summary=torch.zeros(F * SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+        torch.cuda.synchronize(dev)
+        with LpfContext(0) as ctx:
+            ctx.set_pipelined(mode)
+            ctx.set_camera(T, K, W, H, 0.0, 60.0)
+            for _ in range(3):
+                ctx.set_mask_rects(d_rects)
+                ctx.set_masks(d_masks, lend=True)
+                ctx.run_device(d_pts, off, inst_cap=cap, **o)
+            ctx.sync()
+        sm = np.frombuffer(o["summary"].cpu().numpy().tobytes(), SUMMARY_DTYPE)
+        lab, vidx, inst = o["label_bits"].cpu().numpy().view(np.uint32), o["valid_idx"].cpu().numpy(), o["inst_idx"].cpu().numpy()
+        seen = 0
+        for f in range(F):
+            ref = orc.run(clouds[f], T, K, W, H, 0.0, 60.0, label_img=orc.pack_masks(expect[f], 0, H, W), M=M, want_float=False)
+            a = int(off[f])
+            assert np.array_equal(lab[a:a + sizes[f]], ref["label_bits"]), (cam, mode, F, f)
+            assert np.array_equal(vidx[a:a + ref["n_valid"]], ref["valid_idx"]), (cam, mode, F, f)
+            assert np.array_equal(sm[f]["inst_count"][:M], ref["inst_count"]), (cam, mode, F, f)
+            for m in range(M):
+                lo, hi = int(sm[f]["inst_off"][m]), int(sm[f]["inst_off"][m + 1])
+                assert np.array_equal(inst[f, lo:hi], ref["inst_lists"][m]), (cam, mode, F, f, m)
+            seen += int(ref["inst_count"].sum())
+        assert seen > (100 if W > 100 else 0), (cam, F, seen)
