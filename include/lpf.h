@@ -198,6 +198,8 @@ int lpf_set_masks_u8(lpf_ctx *ctx, const uint8_t *masks, int F, int M, int erode
  *     have a candidate -- no pack, no label image, whatever the launch size; small launches (a frame or a few) read a valid point's M
  *     mask bytes and gate them by the rectangles;
  *   - dense frames' masks are packed, and the pack reads a 16-pixel group of mask m only where it meets m's rectangle.
+ * A rectangle may reach beyond the image (it is read as clipped to it; INT32_MIN / INT32_MAX as "no limit" are fine), x1 <= x0 or
+ * y1 <= y0 is an empty one.
  * The same results as without the hint as long as the caller's word holds; erosion and the other float rules ignore it.  on_device:
  * 0 = host memory, copied now without a wait; otherwise device memory (16-byte aligned) that stays unchanged until the runs that use
  * these masks have completed, like lent masks.  rects = NULL clears a pending hint.  The hint is consumed by the next lpf_set_masks_*. */
