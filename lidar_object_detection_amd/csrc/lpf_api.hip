@@ -441,6 +441,16 @@ int upload(lpf_ctx *c, void *dst, const void *src, size_t bytes)
     return LPF_OK;
 }
 
+// The address a kernel may write for a host pointer that lies in page-locked, GPU-mapped memory (hipHostMalloc / lpf_host_alloc,
+// hipHostRegister), or NULL for any other memory.  Asked every time: the answer for an address can change between calls.
+void *device_alias_of_pinned(void *host)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }    // (plain malloc memory: an error in some runtimes)
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
 // box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) for lpf_points_in_boxes
 void box_params(const double *c, int oriented, double *o)
 {
@@ -1430,6 +1440,34 @@ int lpf_run_batch(lpf_ctx *c, const float *pts, const int64_t *frame_off, int F,
         LPF_D2H(depth, depth, n * 8)
         LPF_D2H(u_f, uf, n * 8)
         LPF_D2H(v_f, vf, n * 8)
+        // Result buffers in page-locked memory (lpf_host_alloc, hipHostMalloc): the filled parts of the compact results are written
+        // there by a kernel that reads the lengths from the summaries on the device -- one launch and ONE host wait, where the copy
+        // engine needs the summaries on the host first (a wait), four copies per frame and a second wait.
+        {
+            LpfToHost D;
+            memset(&D, 0, sizeof D);
+            bool r2h = out->summary != nullptr && (out->valid_idx || out->inst_idx);
+            auto alias = [&](void *host, void **dev) {
+                *dev = host ? device_alias_of_pinned(host) : nullptr;
+                if (host && !*dev) r2h = false;
+            };
+            if (r2h) {
+                alias(out->summary, &D.summary);
+                alias(out->valid_idx, (void **)&D.valid_idx);
+                alias(out->uv_valid, (void **)&D.uv_valid);
+                alias(out->label_valid, (void **)&D.label_valid);
+                alias(out->inst_idx, (void **)&D.inst_idx);
+                alias(out->count_mb, (void **)&D.count_mb);
+            }
+            if (r2h) {
+                D.inst_cap = out->inst_cap;
+                D.n_count = out->count_mb ? M * Btot : 0;
+                hipLaunchKernelGGL(lpf_results_to_host, dim3((unsigned)F * LPF_R2H_BLOCKS), dim3(LPF_BLOCK), 0, c->stream, P, D);
+                LPF_HIP(c, hipGetLastError());
+                LPF_HIP(c, host_wait(c));
+                return LPF_OK;
+            }
+        }
         LPF_D2H(count_mb, count_out, (size_t)M * Btot * 4)
         // lists: fetch the summary first, then only the filled part of each list
         std::vector<lpf_frame_summary> hs((size_t)F);

@@ -1672,6 +1672,47 @@ __global__ __launch_bounds__(LPF_BLOCK) void lpf_resize_linear_u8_kernel(const u
     dst[i] = (uint8_t)((((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// ------------------------------------------------------------------------------------
+// Host callers whose result buffers are page-locked (lpf_host_alloc / hipHostMalloc: the GPU can write them): the filled parts of the
+// compact results -- valid_idx, (u, v) and labels of the valid points, the instance lists, the counts, the summaries -- go to host
+// memory by THIS kernel, which reads the lengths from the summaries on the device.  The copy engine needs the lengths on the host
+// first: a host wait, then four copies per frame (each ~10 us of latency for a few hundred KB) and a second wait -- most of what a
+// frame's host call cost once the kernels take 20 us.  LPF_R2H_BLOCKS blocks per frame, 8-byte stores (every array is 8-byte aligned
+// at a frame's offset except the 4-byte labels, which go word by word).
+// ------------------------------------------------------------------------------------
+#define LPF_R2H_BLOCKS 8
+struct LpfToHost {
+    long long *valid_idx; int2 *uv_valid; uint32_t *label_valid; long long *inst_idx; int32_t *count_mb; void *summary;   // host (mapped), nullable
+    long long inst_cap;
+    int n_count;                 // M * Btot
+};
+
+__global__ __launch_bounds__(LPF_BLOCK) void lpf_results_to_host(const LpfParams P, const LpfToHost D)
+{
+    const int f = (int)blockIdx.x / LPF_R2H_BLOCKS, part = (int)blockIdx.x - f * LPF_R2H_BLOCKS;
+    if (f >= P.F) return;
+    const LpfFrame fr = lpf_frame_record(P.frame0, P.frames, P.F > 1, f);
+    const long long *S = reinterpret_cast<const long long *>(static_cast<const char *>(P.summary) + (size_t)f * LPF_SUMMARY_BYTES);   // (layout: lpf_finalize_frame)
+    const long long nv = S[0];
+    long long tot = S[34 + LPF_MAX_MASKS_DEV];                // inst_off[M_max] = entries of all lists
+    if (tot > D.inst_cap) tot = D.inst_cap;
+    const long long t0 = (long long)part * LPF_BLOCK + threadIdx.x, step = (long long)LPF_R2H_BLOCKS * LPF_BLOCK;
+    const long long a = fr.pt_off;
+    if (D.valid_idx) for (long long i = t0; i < nv; i += step) D.valid_idx[a + i] = P.valid_idx[a + i];
+    if (D.uv_valid) for (long long i = t0; i < nv; i += step) D.uv_valid[a + i] = P.uv_valid[a + i];
+    if (D.label_valid) for (long long i = t0; i < nv; i += step) D.label_valid[a + i] = P.label_valid[a + i];
+    if (D.inst_idx) {
+        const long long b = (long long)f * D.inst_cap;
+        for (long long i = t0; i < tot; i += step) D.inst_idx[b + i] = P.inst_idx[b + i];
+    }
+    if (part == 0) {
+        long long *dst = reinterpret_cast<long long *>(static_cast<char *>(D.summary) + (size_t)f * LPF_SUMMARY_BYTES);
+        for (int i = threadIdx.x; i < LPF_SUMMARY_BYTES / 8; i += LPF_BLOCK) dst[i] = S[i];
+    }
+    if (D.count_mb)                                            // one array for the whole batch: dealt over all blocks
+        for (long long i = (long long)blockIdx.x * LPF_BLOCK + threadIdx.x; i < D.n_count; i += (long long)gridDim.x * LPF_BLOCK) D.count_mb[i] = P.count_out[i];
+}
+
 // The one case cv2.resize(..., INTER_LINEAR) does not compute linearly: a source of exactly twice the target in BOTH axes is handed to
 // INTER_AREA (resize(): `if (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation =
 // INTER_AREA`), whose 8-bit single-channel 2 x 2 path (ResizeAreaFastVec, scalar and SIMD alike) is the rounded mean of the four

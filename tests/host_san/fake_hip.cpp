@@ -33,6 +33,7 @@ hipError_t hipMalloc(void **p, size_t n) { *p = calloc(n ? n : 1, 1); return *p 
 hipError_t hipFree(void *p) { free(p); return 0; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 hipError_t hipHostFree(void *p) { free(p); return 0; }
+hipError_t hipPointerGetAttributes(void *, const void *) { return 1; }      // (nothing is GPU-mapped here: host results take the copy path)
 hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { ++g_copies; memmove(d, s, n); return 0; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { ++g_copies; memmove(d, s, n); return 0; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
