@@ -876,7 +876,8 @@ class LpfContext:
             if want_lists:
                 r["valid_idx"] = vidx[a:a + r["n_valid"]]
                 if uvv is not None:
-                    r["u_valid"], r["v_valid"] = uvv[a:a + r["n_valid"], 0], uvv[a:a + r["n_valid"], 1]
+                    r["uv_valid"] = uvv[a:a + r["n_valid"]]                      # contiguous [n_valid, 2]; u / v are its columns
+                    r["u_valid"], r["v_valid"] = r["uv_valid"][:, 0], r["uv_valid"][:, 1]
                     r["label_valid"] = labv[a:a + r["n_valid"]]
                 r["inst_lists"] = [iidx[f, int(s["inst_off"][m]):int(s["inst_off"][m + 1])] for m in range(M)] \
                     if iidx is not None else []

@@ -983,7 +983,7 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
         # (the result arrays live in page-locked buffers the context reuses: what outlives this call is copied out of them here -- the
         #  compact lists, a few hundred KB -- and the gathers / casts of the reference's types are made from those copies when read)
         vi = r["valid_idx"].copy()
-        uvv = np.stack([r["u_valid"], r["v_valid"]])                     # int32 [2, n_valid]
+        uvv = r["uv_valid"].copy()                                       # int32 [n_valid, 2]: one contiguous copy
         labv = r["label_valid"].copy()
         lists = [l.copy() for l in r["inst_lists"][:m]]
         is_scan = isinstance(f.points, Scan)
@@ -995,7 +995,7 @@ def run_frames(frames, TrVeloToRect, camera, depth_max=50.0, min_points=10, use_
             stats = stats_from_counts(r["inst_count"][:m], r["count_mb"][:m], f.colors, min_points, pos)
             for d in stats:
                 d.pop("_best_col"), d.pop("_best_count")
-        lazy = dict(u_valid=lambda uvv=uvv: uvv[0].astype(np.int64), v_valid=lambda uvv=uvv: uvv[1].astype(np.int64),
+        lazy = dict(u_valid=lambda uvv=uvv: uvv[:, 0].astype(np.int64), v_valid=lambda uvv=uvv: uvv[:, 1].astype(np.int64),
                     points_valid=lambda p=host_pts, vi=vi: p[vi, :3],
                     car_point_sets=lambda p=host_pts, ls=lists: [p[l, :3] if len(l) else np.array([]).reshape(0, 3) for l in ls],
                     bg_assigned=lambda labv=labv: labv != 0)
