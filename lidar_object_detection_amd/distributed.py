@@ -190,10 +190,11 @@ def process_frames_distributed(seq=0, cam_id=0, segmenter=None, image_loader=Non
     todo = velo.available_frames() if frames is None else list(frames)
 
     def process_local(my_frames):
-        items = pipeline.collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, my_frames)
+        items = pipeline.iter_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, my_frames,
+                                           boxes_as_arrays=True)                  # (only the statistics leave this function)
         out = {}
-        for i in range(0, len(items), batch_frames):
-            res = pipeline.run_frames(items[i:i + batch_frames], velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, local_rank)
+        for batch in pipeline._batches(items, batch_frames):                        # one batch of the shard in memory at a time
+            res = pipeline.run_frames(batch, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, local_rank)
             out.update({r["frame"]: r["car_statistics"] for r in res if r["n_valid"] > 0})
         return out
 

@@ -1093,13 +1093,32 @@ def _boxes_of_file(json_path, camera, velo_to_cam, keep_all=False, parsed=None):
 
 def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None,
                          keep_all_boxes=False, boxes_as_arrays=False):
-    """The reference's per-frame loading + skip rules (cvs_erosion.py:320-369): a frame is
-    dropped when its scan, its box file, its image or its detections are missing."""
+    """iter_frame_inputs as a list (every frame's scan and masks in memory at once: for a handful of frames)."""
+    return list(iter_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames,
+                                  keep_all_boxes, boxes_as_arrays))
+
+
+def _batches(items, n):
+    """Lists of up to n consecutive items of an iterable, made as they are asked for."""
+    batch = []
+    for it in items:
+        batch.append(it)
+        if len(batch) >= n:
+            yield batch
+            batch = []
+    if batch:
+        yield batch
+
+
+def iter_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames=None,
+                      keep_all_boxes=False, boxes_as_arrays=False):
+    """The reference's per-frame loading + skip rules (cvs_erosion.py:320-369), one FrameInputs at a time: a frame is
+    dropped when its scan, its box file, its image or its detections are missing.  (A generator: a frame loop over a whole drive
+    holds one batch of scans and masks, not the drive.)"""
     sequence = "2013_05_28_drive_%04d_sync" % seq
     bbox_dir = os.path.join(kitti360_path, "bboxes_3D_cam0")
     todo = velo.available_frames() if frames is None else list(frames)
     print(f"Found {len(todo)} frames to process")
-    items = []
     for frame in todo:
         print(f"\nProcessing frame {frame}...")
         try:
@@ -1124,18 +1143,19 @@ def collect_frame_inputs(kitti360_path, seq, cam_id, segmenter, image_loader, ca
         _, masks, colors, boxes_2d, _ = seg
         if masks is None or len(masks) == 0:
             continue
-        items.append(FrameInputs(frame, points, masks, boxes, colors, boxes_2d))
-    return items
+        yield FrameInputs(frame, points, masks, boxes, colors, boxes_2d)
 
 
 def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_path=None,
                    master_csv_path="results/master_car_statistics.csv", frames=None, batch_frames=32,
-                   erode_iters=0, v3_pipeline=False, device=0, timestamp=None, read_ahead=False):
+                   erode_iters=0, v3_pipeline=False, device=0, timestamp=None, read_ahead=True):
     """cvs_erosion.process_frames (cvs_erosion.py:298-379): writes the master CSV and prints the
     overall analysis.  ``segmenter(image) -> (img, masks, colors, boxes, confidences)`` is the
     YOLO stage (unchanged subsystem); pass masks it already eroded, or raw masks plus
-    ``erode_iters=1, v3_pipeline=True`` to erode on the GPU.  ``read_ahead=True`` processes frame
-    by frame with the native scan reader fetching the next files meanwhile (same CSV)."""
+    ``erode_iters=1, v3_pipeline=True`` to erode on the GPU.  ``read_ahead=True`` (the default) processes frame
+    by frame, as the reference's loop does -- each frame's rows are appended before the next frame is looked at -- with the native
+    reader fetching the next scans and parsing the next box files meanwhile; ``read_ahead=False`` reads ``batch_frames`` frames with
+    NumPy and runs them as one launch (same CSV; its lines are printed batch by batch)."""
     if segmenter is None:
         raise ValueError("process_frames needs the segmentation callable (YOLO stays outside this package)")
     root = kitti360_path or os.environ["KITTI360_DATASET"]
@@ -1167,9 +1187,9 @@ def process_frames(seq=0, cam_id=0, segmenter=None, image_loader=None, kitti360_
             if r["n_valid"] and r["car_statistics"]:
                 append_to_master_csv(r["car_statistics"], r["frame"], master_csv_path, timestamp)
         return analyze_master_csv(master_csv_path)
-    items = collect_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames, boxes_as_arrays=True)
-    for i in range(0, len(items), batch_frames):
-        for r in run_frames(items[i:i + batch_frames], velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
+    items = iter_frame_inputs(root, seq, cam_id, segmenter, image_loader, camera, velo_to_cam, velo, frames, boxes_as_arrays=True)
+    for batch in _batches(items, batch_frames):              # (one batch of scans and masks in memory at a time)
+        for r in run_frames(batch, velo_to_rect, camera, 50.0, 10, True, erode_iters, v3_pipeline, device):
             if r["n_valid"] == 0:
                 continue
             if r["car_statistics"]:

@@ -185,17 +185,17 @@ def test_process_frames_entry_point(calib, tmp_path, monkeypatch):
     csv_path = str(tmp_path / "results" / "master_car_statistics.csv")
     with contextlib.redirect_stdout(io.StringIO()) as out:
         df = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root),
-                                     master_csv_path=csv_path, timestamp="T")
+                                     master_csv_path=csv_path, timestamp="T", read_ahead=False, batch_frames=2)   # (three batches)
     got = [(int(a), int(b), int(c), int(d), int(e)) for a, b, c, d, e in
            zip(df["frame"], df["car_id"], df["matched_bbox_id"], df["total_points"], df["points_inside_bbox"])]
     assert got == expect and len(expect) > 5
     text = out.getvalue()
     assert "Found 6 frames to process" in text and "No bounding boxes found" in text and "OVERALL ANALYSIS" in text
-    # the same run frame by frame with the native read-ahead scan reader: same rows, same file
+    # the same run frame by frame with the native read-ahead reader (the default): same rows, same file
     csv2 = str(tmp_path / "results2" / "master_car_statistics.csv")
     with contextlib.redirect_stdout(io.StringIO()) as out2:
         df2 = pipeline.process_frames(0, 0, segmenter=segmenter, image_loader=lambda p: p, kitti360_path=str(root),
-                                      master_csv_path=csv2, timestamp="T", read_ahead=True)
+                                      master_csv_path=csv2, timestamp="T")
     assert open(csv2).read() == open(csv_path).read() and df2.equals(df)
     assert "Found 6 frames to process" in out2.getvalue() and "OVERALL ANALYSIS" in out2.getvalue()
     assert "No bounding boxes found" in out2.getvalue() and sorted(out2.getvalue().replace("results2", "results").splitlines()) == sorted(text.splitlines())   # the same lines
