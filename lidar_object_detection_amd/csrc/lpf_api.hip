@@ -448,7 +448,9 @@ void *device_alias_of_pinned(void *host)
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof at);
     if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }    // (plain malloc memory: an error in some runtimes)
-    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    // (hostPointer == host: the answer is about THIS address -- a pointer into the middle of an allocation is only taken when the runtime
+    //  says so itself, never by assuming that its device alias lies at the same offset)
+    return (at.type == hipMemoryTypeHost && at.hostPointer == host) ? at.devicePointer : nullptr;
 }
 
 // box parameters in the oracle's arithmetic (oracle/lpf_oracle.c: orc_oriented_inside) for lpf_points_in_boxes

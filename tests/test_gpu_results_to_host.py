@@ -70,3 +70,56 @@ def test_pinned_results_equal_the_copy_path(calib, mode):
         a = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in a]
         b = ctx.run_batch([clouds[3]], pinned=False, want_valid_uv=True)
         _same(a, b, ("no masks",))
+
+
+def test_result_buffers_inside_one_page_locked_arena(calib):
+    """A C host that carves its result buffers out of ONE page-locked allocation (pointers into the middle of it): whichever way the
+    library takes for them, every buffer holds exactly its own results and not a byte outside it is touched."""
+    import ctypes
+    from lidar_object_detection_amd import synthetic as S
+    from lidar_object_detection_amd._native import LpfContext, Outputs, SUMMARY_DTYPE
+    _, T, K, W, H = S.default_calibration(calib)
+    sc = S.scene(70_000, n_masks=4, n_boxes=5, seed=777, calib=calib)
+    n, M, B = len(sc["points"]), 4, 5
+    with LpfContext(0) as ctx:
+        ctx.set_camera(T, K, W, H, 0.0, 45.0)
+        ctx.set_masks(sc["masks"][None])
+        ctx.set_boxes([sc["corners_velo"]])
+        want = ctx.run_batch([sc["points"]], want_uv=False, want_label=False, want_valid_uv=True)[0]
+        lib = ctx._lib
+        sizes = dict(summary=SUMMARY_DTYPE.itemsize, valid_idx=8 * n, uv_valid=8 * n, label_valid=4 * n, inst_idx=8 * n, count_mb=4 * M * B)
+        gap = 4096
+        total = gap + sum(v + gap for v in sizes.values())
+        base = lib.lpf_host_alloc(total)
+        assert base
+        try:
+            arena = np.frombuffer((ctypes.c_uint8 * total).from_address(base), dtype=np.uint8)
+            arena[:] = 0xA5
+            off, at = {}, gap
+            for k, v in sizes.items():
+                off[k] = at
+                at += v + gap
+            o = Outputs()
+            o.on_device = 0
+            for k in sizes:
+                setattr(o, k, base + off[k])
+            o.inst_cap = n
+            pts = np.ascontiguousarray(sc["points"], dtype=np.float32)
+            foff = np.array([0, n], np.int64)
+            ctx._check(lib.lpf_run_batch(ctx._h, pts.ctypes.data, foff.ctypes.data, 1, 0, ctypes.byref(o)))
+            view = lambda k, dt: arena[off[k]:off[k] + sizes[k]].view(dt)                      # noqa: E731
+            sm = view("summary", SUMMARY_DTYPE)[0]
+            nv, tot = int(sm["n_valid"]), int(sm["inst_off"][32])
+            assert nv == want["n_valid"] and np.array_equal(view("valid_idx", np.int64)[:nv], want["valid_idx"])
+            assert np.array_equal(view("uv_valid", np.int32).reshape(-1, 2)[:nv], want["uv_valid"])
+            assert np.array_equal(view("label_valid", np.uint32)[:nv], want["label_valid"])
+            assert np.array_equal(view("inst_idx", np.int64)[:tot], np.concatenate(want["inst_lists"]))
+            assert np.array_equal(view("count_mb", np.int32).reshape(M, B), want["count_mb"])
+            # nothing beyond the filled parts, nothing between the buffers
+            assert (view("valid_idx", np.uint8)[8 * nv:] == 0xA5).all() and (view("inst_idx", np.uint8)[8 * tot:] == 0xA5).all()
+            guard = np.ones(total, bool)
+            for k, v in sizes.items():
+                guard[off[k]:off[k] + v] = False
+            assert (arena[guard] == 0xA5).all()
+        finally:
+            lib.lpf_host_free(base)
