@@ -292,3 +292,18 @@ def test_frame_result_is_a_dict_whose_gathers_wait_until_read():
     r["car_point_sets"] += [2]
     assert r["car_point_sets"] == [1, 2]
     assert type(pickle.loads(pickle.dumps(r))) is dict and sorted(copy.deepcopy(r)) == sorted(r.keys()) and type(r.copy()) is dict
+
+
+def test_batches_are_made_as_they_are_asked_for():
+    """process_frames(read_ahead=False) and the sharded run read one batch of frames at a time: _batches pulls from its source only what
+    the batch in hand needs."""
+    pulled = []
+
+    def source():
+        for i in range(7):
+            pulled.append(i)
+            yield i
+    it = pipeline._batches(source(), 3)
+    assert next(it) == [0, 1, 2] and pulled == [0, 1, 2]
+    assert next(it) == [3, 4, 5] and pulled == [0, 1, 2, 3, 4, 5]
+    assert list(it) == [[6]] and list(pipeline._batches([], 4)) == [] and list(pipeline._batches([1, 2], 2)) == [[1, 2]]
